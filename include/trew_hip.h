@@ -1,0 +1,171 @@
+/*
+ * trew_hip.h -- C ABI of the MI355X-native TREW scan (libtrew_hip.so).
+ *
+ * Drop-in boundary for the hot path of Chemical118/TREW (reference @ 2025-02-18):
+ * the per-read tandem-repeat detector of src/kmer.cpp.  The reference has no
+ * FFI; its de-facto seam is the kmer.h function set between trew.cpp and
+ * kmer.cpp.  Each entry point below names the
+ * reference interface it replaces.  Plain pointers and sizes only; no C++ or
+ * torch types.  All functions return 0 on success, non-zero on error
+ * (trew_hip_last_error() gives the text); the CLI layer turns a non-zero status
+ * into the reference's "message on stderr + exit(EXIT_FAILURE)" convention
+ * (kmer.cpp:84-87, 1007-1008).
+ *
+ * Packed read format ("bit planes", produced by trew_pack_reads or by the
+ * device-side generator): a read of n bases occupies 3*ceil(n/32) 32-bit words,
+ * one {lo, hi, nmask} triple per 32 bases; bit i of a triple's words describes
+ * base 32*j+i.  code = 2*hi+lo with T=0 G=1 C=2 A=3 (codes[], kmer.cpp:14-31);
+ * nmask bit = 1 for any other byte (N, lower/upper IUPAC, '\r', bytes >= 0x80).
+ * Bits past the end of the read are zero in lo/hi and may be anything in nmask.
+ */
+#ifndef TREW_HIP_H
+#define TREW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TREW_HIP_ABI_VERSION 1
+
+/* scan modes: which per-read driver of the reference is reproduced */
+enum {
+    TREW_MODE_SHORT = 0,   /* buffer_task       kmer.cpp:80-266  (trew short)              */
+    TREW_MODE_PAIR = 1,    /* buffer_task_pair  kmer.cpp:268-745 (trew short --paired_end) */
+    TREW_MODE_LONG = 2,    /* buffer_task_long  kmer.cpp:747-985 (trew long)               */
+    TREW_MODE_SEGMENT = 3  /* k_mer_check on every read as one segment, kmer.h:232-236     */
+};
+
+/* result tables: ResultMapData = {forward, backward, both} x {high(first), low(second)}, kmer.h:79-81 */
+enum {
+    TREW_TABLE_FORWARD_HIGH = 0,
+    TREW_TABLE_FORWARD_LOW = 1,
+    TREW_TABLE_BACKWARD_HIGH = 2,
+    TREW_TABLE_BACKWARD_LOW = 3,
+    TREW_TABLE_BOTH_HIGH = 4,
+    TREW_TABLE_BOTH_LOW = 5,
+    TREW_NUM_TABLES = 6
+};
+
+/* debug / test flags for trew_hip_params.flags */
+enum {
+    TREW_FLAG_NO_FILTER = 1 /* skip the bucket-bound prefilter: every k is a candidate (exact path only) */
+};
+
+/* Replaces the eight configuration globals MIN_MER ... HIGH_BASELINE
+ * (kmer.h:55-63, set in trew.cpp:165-172, 246-253). */
+typedef struct {
+    int32_t min_mer;          /* MIN_MER, >= 3 (ABS_MIN_MER)                                  */
+    int32_t max_mer;          /* MAX_MER, <= 32 on the device path of this ABI version        */
+    double low_baseline;      /* LOW_BASELINE  (-L)                                           */
+    double high_baseline;     /* HIGH_BASELINE (-H)                                           */
+    int32_t slice_length;     /* SLICE_LENGTH (-s), long mode only                            */
+    int32_t mode;             /* TREW_MODE_*                                                  */
+    int32_t device;           /* HIP device ordinal                                           */
+    int32_t n_slots;          /* batch slots (one HIP stream each), >= 1                      */
+    uint64_t max_batch_words; /* capacity of one slot's packed-read buffer, 32-bit words      */
+    uint64_t max_batch_reads; /* capacity of one slot, reads (pairs count as two)             */
+    uint32_t table_log2_slots;/* device count table: 2^table_log2_slots entries (>= 12)       */
+    uint32_t flags;           /* TREW_FLAG_*                                                  */
+} trew_hip_params;
+
+/* Replaces QueueData / PairQueueData + LocationVector (kmer.h:73, 93-103): one
+ * chunk of reads handed to the consumer.  The caller keeps ownership of every
+ * pointer until trew_hip_wait(slot) returns.  With on_device != 0 the pointers
+ * are device pointers and nothing is copied. */
+typedef struct {
+    const uint32_t *words;    /* packed triples                                               */
+    uint64_t n_words;
+    const uint32_t *offsets;  /* word offset of each read, or NULL: read r starts at r*uniform_stride */
+    const uint32_t *lengths;  /* bases of each read, or NULL: every read has uniform_length   */
+    uint32_t uniform_length;
+    uint32_t uniform_stride;
+    uint64_t n_reads;         /* number of reads; in pair mode reads 2i and 2i+1 are mates (R1, R2) */
+    int32_t on_device;
+    int32_t max_length;       /* on_device + lengths only: longest read of the batch (0 = unknown) */
+} trew_hip_batch;
+
+/* one (k, word) -> count row; word = the 2k-bit k-mer, first base most
+ * significant (KmerSeq, kmer.h:77); word_hi is 0 for k <= 32. */
+typedef struct {
+    int32_t k;
+    int32_t table;
+    uint64_t word_lo;
+    uint64_t word_hi;
+    uint64_t count;
+} trew_hip_row;
+
+typedef struct trew_hip_ctx trew_hip_ctx;
+
+/* Replaces set_extract_k_mer / set_rotation_table / ThreadData set-up,
+ * trew.cpp:382-406: allocates streams, device buffers, the count table. */
+int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out);
+void trew_hip_destroy(trew_hip_ctx *ctx);
+const char *trew_hip_last_error(const trew_hip_ctx *ctx); /* ctx may be NULL: last init error */
+
+/* Replaces one pop+process iteration of buffer_task* (kmer.cpp:106-177):
+ * asynchronously copies the batch (unless on_device), runs the prefilter and
+ * the exact kernel on the slot's stream, accumulating into the device tables. */
+int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot);
+/* Blocks until the slot's work is done (tasks.wait, kmer.cpp:1323-1325). */
+int trew_hip_wait(trew_hip_ctx *ctx, int slot);
+
+/* Replaces the thread merge of process_output (kmer.cpp:1486-1515): waits for
+ * every slot and returns the rows of one table (any order).  *n_rows receives
+ * the number of rows in the table even when it exceeds cap. */
+int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows, uint64_t cap, uint64_t *n_rows);
+/* Clears the six tables (start of a new file, kmer.cpp:89). */
+int trew_hip_reset_tables(trew_hip_ctx *ctx);
+/* Adds rows (e.g. another rank's tables) into the device tables. */
+int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_rows);
+
+/* Per-read results of the last submit on `slot` (after trew_hip_wait): for
+ * TREW_MODE_SEGMENT the (k_high, k_low, MAX_SEQ at k_high, MAX_SEQ at k_low)
+ * that k_mer_check returns / reports through repeat_seq (kmer.cpp:2260-2262,
+ * 2327).  Arrays of n_reads entries; any may be NULL. */
+int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,
+                             uint64_t *seq_high, uint64_t *seq_low, uint64_t n_reads);
+/* Candidate-k masks of the prefilter for the last submit on `slot`: bit (k-1)
+ * of cand[r*slots_per_read + s] is set when k survived for segment s of read r.
+ * Diagnostic: used to test that the prefilter never drops a passing k. */
+int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *batch, uint64_t *cand, int slots_per_read);
+
+/* Kernel timings of the last submit on `slot` (HIP events on the slot's
+ * stream), milliseconds; n_flagged = reads the prefilter passed to the exact kernel. */
+int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filter, float *ms_exact, uint64_t *n_flagged);
+
+/* ---- host-side packing: the codes[] lookup of kmer.cpp:14-31 applied once per base ---- */
+/* words needed for a read of n bases */
+uint64_t trew_pack_words(uint64_t n_bases);
+/* Packs n reads given as inclusive [st,nd] byte ranges of buf (LocationVector,
+ * kmer.h:73) into words/offsets/lengths; returns the words written, or
+ * (uint64_t)-1 if words_cap is too small. */
+uint64_t trew_pack_reads(const char *buf, const int64_t *st, const int64_t *nd, uint64_t n_reads,
+                         uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths);
+
+/* ---- synthetic workloads of SURVEY.md section 8(d); identical on host and device ---- */
+/* short reads, TTAGGG-seeded: 1.0 % telomeric, 0.5 % junction, 1 % substitutions in those,
+ * N with p = 5e-4.  Host: ASCII rows of read_len bytes + '\n'. */
+int trew_synth_short_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, char *out);
+/* Device: packed triples, read r at word offset r*3*ceil(read_len/32), written to device memory. */
+int trew_synth_short_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                            uint32_t read_len, uint32_t *d_words);
+/* paired fragments (config 3): R1 = first read_len bases of a 2*read_len fragment, R2 = revcomp of the rest.
+ * Host: mate 1 and mate 2 rows; device: reads 2i, 2i+1 are the mates. */
+int trew_synth_pair_ascii(uint64_t seed, uint64_t first_pair, uint64_t n_pairs, uint32_t read_len, char *out1, char *out2);
+int trew_synth_pair_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                           uint32_t read_len, uint32_t *d_words);
+
+/* device memory helpers so that a non-C++ host can keep batches resident */
+int trew_hip_malloc(trew_hip_ctx *ctx, uint64_t bytes, void **d_ptr);
+int trew_hip_free(trew_hip_ctx *ctx, void *d_ptr);
+int trew_hip_memcpy_h2d(trew_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int trew_hip_memcpy_d2h(trew_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int trew_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TREW_HIP_H */

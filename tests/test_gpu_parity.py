@@ -1,0 +1,194 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI.  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import trew_amd as T
+from trew_amd import capi
+from conftest import GOLDEN, read_fastq
+from helpers import EDGE_LENGTHS, edge_reads, mixed_segments
+
+pytestmark = pytest.mark.gpu
+
+KAT32 = ["TTGCATCACACCCTCGCCG", "TTAGGG", "TTAGAGCCCACA", "TTTTGCCCTCATCACACCCTCGCCTCCTTCGC"]
+
+
+@pytest.mark.parametrize("flags", [0, T.FLAG_NO_FILTER])
+@pytest.mark.parametrize("motif", KAT32)
+def test_k_mer_test_kat_on_gpu(motif, flags):
+    # test.cpp:172-214 restated against the HIP path
+    r = T.k_mer_check((motif * 20).encode(), 5, 32, 0.5, 0.8, flags=flags)
+    assert len(r["hist_high"]) == 1
+    (k, w), c = next(iter(r["hist_high"].items()))
+    assert k == len(motif) == r["k_high"]
+    assert min(w, O.rot_seq(O.revcomp(w, k), k)) == O.four_to_int(motif)
+    assert c == len(motif) * 19 + 1
+    assert r == O.segment_check(O.OracleParams(), (motif * 20).encode())
+
+
+def test_survey_segment_vector_on_gpu():
+    s = "TTAGGG" * 7 + "TTANGG" + "TTAGGG" + "TTAGGC" + "TTAGGG" * 2 + "TTA"
+    r = T.k_mer_check(s.encode(), 5, 18)
+    assert (r["k_high"], r["k_low"], r["seq_high"]) == (6, 6, 213)
+    assert {O.int_to_four(w, k): c for (k, w), c in r["hist_high"].items()} == {"TTAGGG": 58, "TTAGGC": 6}
+
+
+def _segment_parity(segs, min_mer, max_mer, low, high, flags):
+    p = O.OracleParams(min_mer=min_mer, max_mer=max_mer, low=low, high=high)
+    exp = [O.segment_check(p, s) for s in segs]
+    with T.TrewHip(mode=T.MODE_SEGMENT, min_mer=min_mer, max_mer=max_mer, low=low, high=high, flags=flags,
+                   max_batch_reads=len(segs) + 8, max_batch_words=1 << 20) as t:
+        b = t.submit_reads(segs)
+        t.wait()
+        kh, kl, sh, sl = t.segment_results(len(segs))
+        tabs = t.collect()
+    bad = []
+    for i, e in enumerate(exp):
+        got = (int(kh[i]), int(kl[i]), int(sh[i]), int(sl[i]))
+        want = (e["k_high"], e["k_low"], e["seq_high"], e["seq_low"])
+        if got != want:
+            bad.append((i, segs[i], got, want))
+    assert not bad, bad[:5]
+    want_h, want_l = {}, {}
+    for e in exp:
+        for key, c in e["hist_high"].items():
+            want_h[key] = want_h.get(key, 0) + c
+        for key, c in e["hist_low"].items():
+            want_l[key] = want_l.get(key, 0) + c
+    assert tabs["forward_high"] == want_h
+    assert tabs["forward_low"] == want_l
+    return exp
+
+
+@pytest.mark.parametrize("flags", [0, T.FLAG_NO_FILTER])
+def test_segment_parity_mixed(flags):
+    segs = mixed_segments(11, 1500, [20, 33, 64, 75, 76, 95, 96, 100, 149])
+    exp = _segment_parity(segs, 5, 32, 0.5, 0.8, flags)
+    assert sum(1 for e in exp if e["k_high"]) > 200 and sum(1 for e in exp if e["k_low"]) > 300
+
+
+def test_segment_parity_long_segments():
+    segs = mixed_segments(12, 300, [150, 160, 299, 320, 500, 640, 1000, 1023])
+    _segment_parity(segs, 5, 32, 0.5, 0.8, 0)
+
+
+@pytest.mark.parametrize("mn,mx,low,high", [(3, 12, 0.5, 0.8), (5, 32, 0.3, 0.6), (8, 20, 0.7, 0.95), (6, 6, 0.5, 0.5), (5, 32, 1.0, 1.0)])
+def test_segment_parity_other_params(mn, mx, low, high):
+    segs = mixed_segments(13, 600, [30, 75, 100, 150])
+    _segment_parity(segs, mn, mx, low, high, 0)
+
+
+def test_filter_is_sound():
+    """The prefilter may keep too much, never too little: every k whose exact
+    MAX/COUNT reaches LOW must be a candidate."""
+    segs = mixed_segments(21, 800, [40, 75, 90, 150, 300])
+    p = O.OracleParams()
+    with T.TrewHip(mode=T.MODE_SEGMENT, max_batch_reads=len(segs) + 8, max_batch_words=1 << 20) as t:
+        b = t.host_batch(*capi.pack_reads(segs))
+        cand = t.filter_masks(b, 1)
+    n_pass = n_cand = 0
+    for i, s in enumerate(segs):
+        st = O.segment_stats(p, s, 5, 32)
+        for k, (cnt, mx, _) in st.items():
+            is_c = (int(cand[i, 0]) >> (k - 1)) & 1
+            n_cand += is_c
+            if cnt and mx / cnt >= 0.5:
+                n_pass += 1
+                assert is_c, (i, k, s)
+    assert n_pass > 500
+    # and it is selective on random sequence
+    rnd = np.random.default_rng(5)
+    rand = ["".join("ACGT"[x] for x in rnd.integers(0, 4, 75)).encode() for _ in range(4000)]
+    with T.TrewHip(mode=T.MODE_SEGMENT, max_batch_reads=5000, max_batch_words=1 << 20) as t:
+        cand = t.filter_masks(t.host_batch(*capi.pack_reads(rand)), 1)
+    assert np.count_nonzero(cand) <= 4
+
+
+def _short_parity(reads, **kw):
+    p = O.OracleParams(**{k: v for k, v in kw.items() if k in ("min_mer", "max_mer", "low", "high")})
+    want = O.run_short(p, reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, **kw) as t:
+        t.submit_reads(reads)
+        t.wait()
+        got = t.collect()
+    for name in T.TABLE_NAMES:
+        assert got[name] == want[name], name
+    return want
+
+
+def test_short_parity_edge_reads():
+    want = _short_parity(edge_reads())
+    assert all(len(want[n]) > 0 for n in T.TABLE_NAMES)
+
+
+def test_short_parity_edge_reads_small_k():
+    _short_parity(edge_reads(5), min_mer=3, max_mer=12)
+
+
+def test_short_parity_synthetic_20k():
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 20000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = _short_parity(reads)
+    assert sum(want["both_high"].values()) > 10000
+
+
+def test_short_fixture_is_empty():
+    reads = read_fastq(os.path.join(GOLDEN, "test.fastq"))
+    want = _short_parity(reads)
+    assert all(len(v) == 0 for v in want.values())
+
+
+def test_device_generator_matches_host():
+    n, L = 5000, 150
+    buf, st, nd = capi.synth_short_ascii(7, 123, n, L)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    words, offs, lens = capi.pack_reads(reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=n, max_batch_words=16) as t:
+        stride = 3 * ((L + 31) // 32)
+        d = t.malloc(n * stride * 4)
+        t.synth_short_device(7, 123, n, L, d)
+        got = t.d2h(d, n * stride * 4).view(np.uint32)
+        # the resident batch scans to the same tables as the host-packed one
+        t.submit(t.device_uniform_batch(d, n, L))
+        t.wait()
+        a = t.collect()
+        t.free(d)
+    assert np.array_equal(got, words)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=n, max_batch_words=len(words) + 8) as t:
+        t.submit(t.host_batch(words, offs, lens))
+        t.wait()
+        b = t.collect()
+    assert a == b == O.run_short(O.OracleParams(), reads)
+
+
+def test_multi_slot_and_reset():
+    buf, st, nd = capi.synth_short_ascii(99, 0, 6000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, n_slots=3, max_batch_reads=2048, max_batch_words=1 << 18) as t:
+        for rep in range(2):
+            for i in range(0, len(reads), 2000):
+                slot = (i // 2000) % 3
+                t.wait(slot)
+                t.submit_reads(reads[i:i + 2000], slot)
+            assert t.collect() == want
+            t.reset_tables()
+        assert all(len(v) == 0 for v in t.collect().values())
+        t.add_rows(want)
+        t.add_rows(want)
+        got = t.collect()
+        assert {n: {k: 2 * c for k, c in want[n].items()} for n in want} == got
+
+
+def test_empty_and_tiny_batches():
+    with T.TrewHip(mode=T.MODE_SHORT) as t:
+        t.submit_reads([])
+        t.wait()
+        t.submit_reads([b"", b"ACG", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN"])
+        t.wait()
+        assert all(len(v) == 0 for v in t.collect().values())
+    with pytest.raises(T.TrewHipError):
+        with T.TrewHip(mode=T.MODE_SHORT) as t:
+            t.submit_reads([b"A" * 1001])

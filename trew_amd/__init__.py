@@ -1,0 +1,19 @@
+"""trew_amd -- MI355X-native telomeric-repeat scanner (hot path of Chemical118/TREW).
+
+The product is the HIP shared library (trew_amd/csrc -> trew_amd/lib/libtrew_hip.so,
+C ABI in include/trew_hip.h) and the C++ `trew` host built on it.  This package
+only binds the C ABI for tests and benchmarks.
+"""
+from . import capi  # noqa: F401
+from .capi import (  # noqa: F401
+    FLAG_NO_FILTER,
+    MODE_LONG,
+    MODE_PAIR,
+    MODE_SEGMENT,
+    MODE_SHORT,
+    TABLE_NAMES,
+    TrewHip,
+    TrewHipError,
+    k_mer_check,
+    pack_reads,
+)

@@ -1,0 +1,282 @@
+"""ctypes binding of include/trew_hip.h (libtrew_hip.so).
+
+This is plumbing for tests and bench.py; the product is the HIP library.  There
+is no CPU fallback here: if the library is missing or no GPU is present, the
+compute entry points raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrew_hip.so")
+
+MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
+FLAG_NO_FILTER = 1
+TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
+
+# every symbol include/trew_hip.h declares
+EXPORTED_SYMBOLS = (
+    "trew_hip_init", "trew_hip_destroy", "trew_hip_last_error", "trew_hip_submit", "trew_hip_wait",
+    "trew_hip_collect", "trew_hip_reset_tables", "trew_hip_add_rows", "trew_hip_segment_results",
+    "trew_hip_filter_masks", "trew_hip_last_timing", "trew_pack_words", "trew_pack_reads",
+    "trew_synth_short_ascii", "trew_synth_short_device", "trew_synth_pair_ascii", "trew_synth_pair_device",
+    "trew_hip_malloc", "trew_hip_free", "trew_hip_memcpy_h2d", "trew_hip_memcpy_d2h", "trew_hip_abi_version",
+)
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("min_mer", C.c_int32), ("max_mer", C.c_int32),
+        ("low_baseline", C.c_double), ("high_baseline", C.c_double),
+        ("slice_length", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32), ("n_slots", C.c_int32),
+        ("max_batch_words", C.c_uint64), ("max_batch_reads", C.c_uint64),
+        ("table_log2_slots", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("words", C.c_void_p), ("n_words", C.c_uint64),
+        ("offsets", C.c_void_p), ("lengths", C.c_void_p),
+        ("uniform_length", C.c_uint32), ("uniform_stride", C.c_uint32),
+        ("n_reads", C.c_uint64), ("on_device", C.c_int32), ("max_length", C.c_int32),
+    ]
+
+
+class Row(C.Structure):
+    _fields_ = [("k", C.c_int32), ("table", C.c_int32), ("word_lo", C.c_uint64), ("word_hi", C.c_uint64),
+                ("count", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """Load libtrew_hip.so (raises OSError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libtrew_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+    lib.trew_hip_abi_version.restype = i32
+    lib.trew_hip_init.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    lib.trew_hip_destroy.argtypes = [vp]
+    lib.trew_hip_destroy.restype = None
+    lib.trew_hip_last_error.argtypes = [vp]
+    lib.trew_hip_last_error.restype = C.c_char_p
+    lib.trew_hip_submit.argtypes = [vp, C.POINTER(Batch), i32]
+    lib.trew_hip_wait.argtypes = [vp, i32]
+    lib.trew_hip_collect.argtypes = [vp, i32, C.POINTER(Row), u64, C.POINTER(u64)]
+    lib.trew_hip_reset_tables.argtypes = [vp]
+    lib.trew_hip_add_rows.argtypes = [vp, C.POINTER(Row), u64]
+    lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, u64]
+    lib.trew_hip_filter_masks.argtypes = [vp, C.POINTER(Batch), vp, i32]
+    lib.trew_hip_last_timing.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(u64)]
+    lib.trew_pack_words.argtypes = [u64]
+    lib.trew_pack_words.restype = u64
+    lib.trew_pack_reads.argtypes = [C.c_char_p, vp, vp, u64, vp, u64, vp, vp]
+    lib.trew_pack_reads.restype = u64
+    lib.trew_synth_short_ascii.argtypes = [u64, u64, u64, C.c_uint32, vp]
+    lib.trew_synth_short_device.argtypes = [vp, u64, u64, u64, C.c_uint32, vp]
+    lib.trew_synth_pair_ascii.argtypes = [u64, u64, u64, C.c_uint32, vp, vp]
+    lib.trew_synth_pair_device.argtypes = [vp, u64, u64, u64, C.c_uint32, vp]
+    lib.trew_hip_malloc.argtypes = [vp, u64, C.POINTER(vp)]
+    lib.trew_hip_free.argtypes = [vp, vp]
+    lib.trew_hip_memcpy_h2d.argtypes = [vp, vp, vp, u64]
+    lib.trew_hip_memcpy_d2h.argtypes = [vp, vp, vp, u64]
+    _lib = lib
+    return lib
+
+
+class TrewHipError(RuntimeError):
+    pass
+
+
+def pack_reads(reads):
+    """codes[] (kmer.cpp:14-31) applied on the host: list of byte strings -> (words, offsets, lengths)."""
+    lib = load()
+    reads = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+    n = len(reads)
+    st = np.zeros(n, dtype=np.int64)
+    nd = np.zeros(n, dtype=np.int64)
+    pos = 0
+    for i, r in enumerate(reads):
+        st[i] = pos
+        nd[i] = pos + len(r) - 1
+        pos += len(r) + 1
+    buf = b"\n".join(reads) + b"\n"
+    cap = int(sum(lib.trew_pack_words(len(r)) for r in reads)) + 8
+    words = np.zeros(cap, dtype=np.uint32)
+    offsets = np.zeros(max(n, 1), dtype=np.uint32)
+    lengths = np.zeros(max(n, 1), dtype=np.uint32)
+    w = lib.trew_pack_reads(buf, st.ctypes.data, nd.ctypes.data, n, words.ctypes.data, cap, offsets.ctypes.data,
+                            lengths.ctypes.data)
+    if w == 2 ** 64 - 1:
+        raise TrewHipError("trew_pack_reads: buffer too small")
+    return words[: int(w)], offsets[:n], lengths[:n]
+
+
+def synth_short_ascii(seed, first_read, n_reads, read_len):
+    """Host side of the synthetic short-read generator: returns (buf, st, nd)."""
+    lib = load()
+    out = np.zeros(n_reads * (read_len + 1), dtype=np.uint8)
+    lib.trew_synth_short_ascii(seed, first_read, n_reads, read_len, out.ctypes.data)
+    st = np.arange(n_reads, dtype=np.int64) * (read_len + 1)
+    nd = st + read_len - 1
+    return out.tobytes(), st, nd
+
+
+def synth_pair_ascii(seed, first_pair, n_pairs, read_len):
+    lib = load()
+    o1 = np.zeros(n_pairs * (read_len + 1), dtype=np.uint8)
+    o2 = np.zeros(n_pairs * (read_len + 1), dtype=np.uint8)
+    lib.trew_synth_pair_ascii(seed, first_pair, n_pairs, read_len, o1.ctypes.data, o2.ctypes.data)
+    st = np.arange(n_pairs, dtype=np.int64) * (read_len + 1)
+    nd = st + read_len - 1
+    return o1.tobytes(), o2.tobytes(), st, nd
+
+
+class TrewHip:
+    """One device context: init / submit / wait / collect."""
+
+    def __init__(self, mode=MODE_SHORT, min_mer=5, max_mer=32, low=0.5, high=0.8, slice_length=150, device=0,
+                 n_slots=2, max_batch_words=1 << 22, max_batch_reads=1 << 18, table_log2_slots=20, flags=0):
+        self.lib = load()
+        self.params = Params(min_mer, max_mer, low, high, slice_length, mode, device, n_slots, max_batch_words,
+                             max_batch_reads, table_log2_slots, flags)
+        self.ctx = C.c_void_p()
+        rc = self.lib.trew_hip_init(C.byref(self.params), C.byref(self.ctx))
+        if rc != 0:
+            raise TrewHipError("trew_hip_init failed (%d): %s" % (rc, self.lib.trew_hip_last_error(None).decode()))
+        self.mode = mode
+        self._keep = {}
+
+    def close(self):
+        if self.ctx:
+            self.lib.trew_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise TrewHipError("%s failed (%d): %s" % (what, rc, self.lib.trew_hip_last_error(self.ctx).decode()))
+
+    # ---- batches ----
+    def host_batch(self, words, offsets, lengths):
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        b = Batch(words.ctypes.data, len(words), offsets.ctypes.data, lengths.ctypes.data, 0, 0, len(offsets), 0, 0)
+        b._keep = (words, offsets, lengths)
+        return b
+
+    def device_uniform_batch(self, d_words, n_reads, read_len):
+        stride = 3 * ((read_len + 31) // 32)
+        return Batch(d_words, n_reads * stride, None, None, read_len, stride, n_reads, 1, read_len)
+
+    def submit(self, batch, slot=0):
+        self._keep[slot] = batch
+        self._chk(self.lib.trew_hip_submit(self.ctx, C.byref(batch), slot), "trew_hip_submit")
+
+    def wait(self, slot=0):
+        self._chk(self.lib.trew_hip_wait(self.ctx, slot), "trew_hip_wait")
+
+    def submit_reads(self, reads, slot=0):
+        b = self.host_batch(*pack_reads(reads))
+        self.submit(b, slot)
+        return b
+
+    # ---- results ----
+    def collect_rows(self, table=-1):
+        n = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_collect(self.ctx, table, None, 0, C.byref(n)), "trew_hip_collect")
+        rows = (Row * max(1, n.value))()
+        self._chk(self.lib.trew_hip_collect(self.ctx, table, rows, n.value, C.byref(n)), "trew_hip_collect")
+        return rows, n.value
+
+    def collect(self):
+        """The six tables as {name: {(k, word): count}}."""
+        rows, n = self.collect_rows(-1)
+        out = {name: {} for name in TABLE_NAMES}
+        for i in range(n):
+            r = rows[i]
+            out[TABLE_NAMES[r.table]][(r.k, (r.word_hi << 64) | r.word_lo)] = int(r.count)
+        return out
+
+    def reset_tables(self):
+        self._chk(self.lib.trew_hip_reset_tables(self.ctx), "trew_hip_reset_tables")
+
+    def add_rows(self, tables):
+        items = [(t, k, w, c) for t, name in enumerate(TABLE_NAMES) for (k, w), c in tables.get(name, {}).items()]
+        rows = (Row * max(1, len(items)))()
+        for i, (t, k, w, c) in enumerate(items):
+            rows[i] = Row(k, t, w & 0xFFFFFFFFFFFFFFFF, w >> 64, c)
+        self._chk(self.lib.trew_hip_add_rows(self.ctx, rows, len(items)), "trew_hip_add_rows")
+
+    def segment_results(self, n_reads, slot=0):
+        kh = np.zeros(n_reads, dtype=np.int32)
+        kl = np.zeros(n_reads, dtype=np.int32)
+        sh = np.zeros(n_reads, dtype=np.uint64)
+        sl = np.zeros(n_reads, dtype=np.uint64)
+        self._chk(self.lib.trew_hip_segment_results(self.ctx, slot, kh.ctypes.data, kl.ctypes.data, sh.ctypes.data,
+                                                    sl.ctypes.data, n_reads), "trew_hip_segment_results")
+        return kh, kl, sh, sl
+
+    def filter_masks(self, batch, slots_per_read):
+        units = batch.n_reads // 2 if self.mode == MODE_PAIR else batch.n_reads
+        cand = np.zeros(max(1, units * slots_per_read), dtype=np.uint64)
+        self._chk(self.lib.trew_hip_filter_masks(self.ctx, C.byref(batch), cand.ctypes.data, slots_per_read),
+                  "trew_hip_filter_masks")
+        return cand[: units * slots_per_read].reshape(units, slots_per_read)
+
+    def last_timing(self, slot=0):
+        a, b, n = C.c_float(), C.c_float(), C.c_uint64()
+        self._chk(self.lib.trew_hip_last_timing(self.ctx, slot, C.byref(a), C.byref(b), C.byref(n)), "trew_hip_last_timing")
+        return a.value, b.value, n.value
+
+    # ---- device memory ----
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.trew_hip_malloc(self.ctx, nbytes, C.byref(p)), "trew_hip_malloc")
+        return p.value
+
+    def free(self, ptr):
+        self._chk(self.lib.trew_hip_free(self.ctx, ptr), "trew_hip_free")
+
+    def d2h(self, ptr, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        self._chk(self.lib.trew_hip_memcpy_d2h(self.ctx, out.ctypes.data, ptr, nbytes), "trew_hip_memcpy_d2h")
+        return out
+
+    def synth_short_device(self, seed, first_read, n_reads, read_len, d_words):
+        self._chk(self.lib.trew_synth_short_device(self.ctx, seed, first_read, n_reads, read_len, d_words),
+                  "trew_synth_short_device")
+
+    def synth_pair_device(self, seed, first_pair, n_pairs, read_len, d_words):
+        self._chk(self.lib.trew_synth_pair_device(self.ctx, seed, first_pair, n_pairs, read_len, d_words),
+                  "trew_synth_pair_device")
+
+
+def k_mer_check(seq, min_mer=5, max_mer=32, low=0.5, high=0.8, flags=0, device=0):
+    """k_mer_check (kmer.h:232-236) on the GPU for one segment; same result shape as the oracle's segment_check."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    with TrewHip(mode=MODE_SEGMENT, min_mer=min_mer, max_mer=max_mer, low=low, high=high, device=device, n_slots=1,
+                 max_batch_words=1 << 12, max_batch_reads=16, table_log2_slots=14, flags=flags) as t:
+        t.submit_reads([seq])
+        t.wait()
+        kh, kl, sh, sl = t.segment_results(1)
+        tabs = t.collect()
+    return dict(k_high=int(kh[0]), k_low=int(kl[0]), seq_high=int(sh[0]), seq_low=int(sl[0]),
+                hist_high=tabs["forward_high"], hist_low=tabs["forward_low"])

@@ -1,0 +1,516 @@
+// trew_capi.cpp -- the extern "C" layer of libtrew_hip.so (see include/trew_hip.h).
+//
+// Host side only: owns the HIP streams, the per-slot device buffers, the device
+// count table, and launches the kernels of trew_kernels.hip.  There is no CPU
+// fallback: every compute entry point fails loudly when HIP is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trew_common.hpp"
+#include "trew_launch.hpp"
+#include "trew_synth.hpp"
+
+using namespace trew;
+
+namespace {
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    u32 *d_words = nullptr;
+    u32 *d_offsets = nullptr;
+    u32 *d_lengths = nullptr;
+    WorkItem *d_wl = nullptr;
+    u32 *d_wl_count = nullptr;
+    SegResults res = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    bool timed = false;
+    u64 n_units = 0;
+};
+
+std::string g_init_error;
+
+}  // namespace
+
+struct trew_hip_ctx {
+    trew_hip_params p;
+    DevParams dp;
+    DevTable table;
+    u64 table_slots = 0;
+    std::vector<Slot> slots;
+    std::string err;
+    int n_cu = 256;
+};
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return (int) e_ ? (int) e_ : -1;                                                      \
+        }                                                                                         \
+    } while (0)
+
+static int fail(trew_hip_ctx *ctx, const std::string &msg) {
+    ctx->err = msg;
+    return -1;
+}
+
+extern "C" int trew_hip_abi_version(void) { return TREW_HIP_ABI_VERSION; }
+
+extern "C" const char *trew_hip_last_error(const trew_hip_ctx *ctx) {
+    return ctx ? ctx->err.c_str() : g_init_error.c_str();
+}
+
+static float conservative_lowf(double low) {
+    float f = (float) (low * (1.0 - 1e-6));
+    f = std::nextafterf(f, 0.0f);
+    return f;
+}
+
+extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) {
+    if (!params || !out) {
+        g_init_error = "trew_hip_init: null argument";
+        return -1;
+    }
+    *out = nullptr;
+    const trew_hip_params &p = *params;
+    // same limits as the reference CLI (trew.cpp:175-228, 256-304) + this ABI version's device limits
+    if (p.min_mer > p.max_mer) { g_init_error = "MIN_MER must not be greater than MAX_MER."; return -1; }
+    if (p.min_mer < 3) { g_init_error = "MIN_MER must be greater than or equal to 3."; return -1; }
+    if (p.max_mer > 32) { g_init_error = "MAX_MER must be less than or equal to 32 on the HIP path (k in (32,64] is not implemented on device yet)."; return -1; }
+    if (!(0 < p.low_baseline && p.low_baseline <= 1) || !(0 < p.high_baseline && p.high_baseline <= 1)) { g_init_error = "Baseline must be in range 0 to 1."; return -1; }
+    if (p.low_baseline > p.high_baseline) { g_init_error = "Low baseline must be smaller than high baseline."; return -1; }
+    if (p.mode < TREW_MODE_SHORT || p.mode > TREW_MODE_SEGMENT) { g_init_error = "unknown mode"; return -1; }
+    if (p.mode == TREW_MODE_LONG) {
+        if (p.slice_length < 2 * p.max_mer) { g_init_error = "SLICE_LENGTH must be greater than or equal to twice of MAX_MER."; return -1; }
+        if (2 * p.slice_length - 1 > kMaxSegBases) { g_init_error = "SLICE_LENGTH must be at most 512 on the HIP path."; return -1; }
+    }
+    if (p.n_slots < 1 || p.n_slots > 16) { g_init_error = "n_slots must be in [1,16]"; return -1; }
+    if (p.table_log2_slots < 12 || p.table_log2_slots > 30) { g_init_error = "table_log2_slots must be in [12,30]"; return -1; }
+    if (p.max_batch_reads == 0 || p.max_batch_reads > 0xfffffff0ull) { g_init_error = "max_batch_reads out of range"; return -1; }
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_init_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return -2;
+    }
+    if (p.device < 0 || p.device >= ndev) { g_init_error = "device ordinal out of range"; return -1; }
+    e = hipSetDevice(p.device);
+    if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return -2; }
+
+    trew_hip_ctx *ctx = new trew_hip_ctx();
+    ctx->p = p;
+    ctx->dp.min_mer = p.min_mer;
+    ctx->dp.max_mer = p.max_mer;
+    ctx->dp.low = p.low_baseline;
+    ctx->dp.high = p.high_baseline;
+    ctx->dp.lowf = conservative_lowf(p.low_baseline);
+    ctx->dp.slice_len = p.slice_length > 0 ? p.slice_length : 150;
+    ctx->dp.mode = p.mode;
+    ctx->dp.flags = p.flags;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, p.device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+
+    auto bail = [&](const char *what, hipError_t er) {
+        g_init_error = std::string(what) + ": " + hipGetErrorString(er);
+        trew_hip_destroy(ctx);
+        return -3;
+    };
+    ctx->table_slots = 1ull << p.table_log2_slots;
+    ctx->table.log2_part_slots = p.table_log2_slots - kTablePartBits;
+    if ((e = hipMalloc((void **) &ctx->table.keys, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table keys)", e);
+    if ((e = hipMalloc((void **) &ctx->table.counts, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table counts)", e);
+    if ((e = hipMalloc((void **) &ctx->table.overflow, 4)) != hipSuccess) return bail("hipMalloc(overflow)", e);
+    if ((e = hipMemset(ctx->table.keys, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->table.counts, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->table.overflow, 0, 4)) != hipSuccess) return bail("hipMemset", e);
+
+    ctx->slots.resize((size_t) p.n_slots);
+    for (auto &s : ctx->slots) {
+        if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if (p.max_batch_words) {
+            // +8 words of slack: load_planes may prefetch one triple past a read's last one
+            if ((e = hipMalloc((void **) &s.d_words, (p.max_batch_words + 8) * 4)) != hipSuccess) return bail("hipMalloc(words)", e);
+        }
+        if ((e = hipMalloc((void **) &s.d_offsets, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(offsets)", e);
+        if ((e = hipMalloc((void **) &s.d_lengths, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(lengths)", e);
+        if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(WorkItem))) != hipSuccess) return bail("hipMalloc(worklist)", e);
+        if ((e = hipMalloc((void **) &s.d_wl_count, 4)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
+        if (p.mode == TREW_MODE_SEGMENT) {
+            if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc((void **) &s.res.seq_high, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc((void **) &s.res.seq_low, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
+        }
+        if ((e = hipEventCreate(&s.e0)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&s.e1)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreate(&s.e2)) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    *out = ctx;
+    return 0;
+}
+
+extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->p.device);
+    for (auto &s : ctx->slots) {
+        if (s.stream) (void) hipStreamSynchronize(s.stream);
+        if (s.d_words) (void) hipFree(s.d_words);
+        if (s.d_offsets) (void) hipFree(s.d_offsets);
+        if (s.d_lengths) (void) hipFree(s.d_lengths);
+        if (s.d_wl) (void) hipFree(s.d_wl);
+        if (s.d_wl_count) (void) hipFree(s.d_wl_count);
+        if (s.res.k_high) (void) hipFree(s.res.k_high);
+        if (s.res.k_low) (void) hipFree(s.res.k_low);
+        if (s.res.seq_high) (void) hipFree(s.res.seq_high);
+        if (s.res.seq_low) (void) hipFree(s.res.seq_low);
+        if (s.e0) (void) hipEventDestroy(s.e0);
+        if (s.e1) (void) hipEventDestroy(s.e1);
+        if (s.e2) (void) hipEventDestroy(s.e2);
+        if (s.stream) (void) hipStreamDestroy(s.stream);
+    }
+    if (ctx->table.keys) (void) hipFree(ctx->table.keys);
+    if (ctx->table.counts) (void) hipFree(ctx->table.counts);
+    if (ctx->table.overflow) (void) hipFree(ctx->table.overflow);
+    delete ctx;
+}
+
+// Longest segment any slot of any read of the batch can have, and validation of
+// the read-length limits (short mode aborts above MAX_SEQ = 1000, kmer.cpp:1006-1009;
+// the build applies the same limit to pair mode).
+static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_seg) {
+    u32 maxlen = 0;
+    if (b->lengths) {
+        if (b->on_device) {
+            maxlen = (u32) b->max_length;  // caller-provided maximum read length
+            if (maxlen == 0) maxlen = kMaxSegBases;
+        } else {
+            for (u64 i = 0; i < b->n_reads; i++) maxlen = std::max(maxlen, b->lengths[i]);
+        }
+    } else {
+        maxlen = b->uniform_length;
+    }
+    const int mode = ctx->p.mode;
+    if ((mode == TREW_MODE_SHORT || mode == TREW_MODE_PAIR) && maxlen > 1000)
+        return fail(ctx, "This mode is designed for short-read sequencing. Please use 'trew long'.");
+    if (mode == TREW_MODE_SEGMENT && maxlen > (u32) kMaxSegBases) return fail(ctx, "segment longer than 1023 bases");
+    u32 ms;
+    if (mode == TREW_MODE_SHORT || mode == TREW_MODE_PAIR) {
+        const u32 half = (maxlen + 1) / 2;
+        const u32 whole = std::min<u32>(maxlen, (u32) (4 * ctx->p.max_mer - 1));
+        ms = std::max(half, whole);
+    } else if (mode == TREW_MODE_LONG) {
+        ms = std::min<u32>(maxlen, (u32) (2 * ctx->dp.slice_len - 1));
+    } else {
+        ms = maxlen;
+    }
+    *max_seg = ms;
+    return 0;
+}
+
+static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevBatch *db) {
+    if (b->n_reads > ctx->p.max_batch_reads) return fail(ctx, "batch has more reads than max_batch_reads");
+    if (ctx->p.mode == TREW_MODE_PAIR && (b->n_reads & 1)) return fail(ctx, "pair mode needs an even number of reads");
+    if (!b->offsets && !b->lengths && b->uniform_stride < 3 * ((b->uniform_length + 31) / 32))
+        return fail(ctx, "uniform_stride smaller than the packed read");
+    if ((b->offsets == nullptr) != (b->lengths == nullptr)) return fail(ctx, "offsets and lengths must both be given or both be NULL");
+    db->uniform_length = b->uniform_length;
+    db->uniform_stride = b->uniform_stride;
+    db->n_reads = b->n_reads;
+    db->n_units = ctx->p.mode == TREW_MODE_PAIR ? b->n_reads / 2 : b->n_reads;
+    if (b->on_device) {
+        db->words = b->words;
+        db->offsets = b->offsets;
+        db->lengths = b->lengths;
+    } else {
+        if (b->n_words > ctx->p.max_batch_words) return fail(ctx, "batch has more words than max_batch_words");
+        HIPCHK(ctx, hipMemcpyAsync(s.d_words, b->words, b->n_words * 4, hipMemcpyHostToDevice, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.d_words + b->n_words, 0, 8 * 4, s.stream));
+        db->words = s.d_words;
+        db->offsets = nullptr;
+        db->lengths = nullptr;
+        if (b->offsets) {
+            HIPCHK(ctx, hipMemcpyAsync(s.d_offsets, b->offsets, b->n_reads * 4, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(ctx, hipMemcpyAsync(s.d_lengths, b->lengths, b->n_reads * 4, hipMemcpyHostToDevice, s.stream));
+            db->offsets = s.d_offsets;
+            db->lengths = s.d_lengths;
+        }
+    }
+    return 0;
+}
+
+extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot) {
+    if (!ctx || !batch) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    Slot &s = ctx->slots[(size_t) slot];
+    u32 max_seg = 0;
+    if (int rc = batch_geometry(ctx, batch, &max_seg)) return rc;
+    DevBatch db;
+    if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
+    s.n_units = db.n_units;
+    s.timed = false;
+    if (db.n_units == 0) return 0;
+    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, 4, s.stream));
+    if (ctx->p.mode == TREW_MODE_SEGMENT) {
+        HIPCHK(ctx, hipMemsetAsync(s.res.k_high, 0, db.n_reads * 4, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.res.k_low, 0, db.n_reads * 4, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.res.seq_high, 0, db.n_reads * 8, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.res.seq_low, 0, db.n_reads * 8, s.stream));
+    }
+    const u32 wl_cap = (u32) ctx->p.max_batch_reads;
+    HIPCHK(ctx, hipEventRecord(s.e0, s.stream));
+    HIPCHK(ctx, launch_filter(s.stream, pick_nw(max_seg), ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
+    HIPCHK(ctx, hipEventRecord(s.e1, s.stream));
+    const u32 grid = (u32) std::min<u64>((u64) ctx->n_cu * 8ull, std::max<u64>(db.n_units, 1));
+    HIPCHK(ctx, launch_exact(s.stream, grid, ctx->dp, db, ctx->table, s.d_wl, s.d_wl_count, wl_cap, s.res));
+    HIPCHK(ctx, hipEventRecord(s.e2, s.stream));
+    s.timed = true;
+    return 0;
+}
+
+extern "C" int trew_hip_wait(trew_hip_ctx *ctx, int slot) {
+    if (!ctx) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->slots[(size_t) slot].stream));
+    return 0;
+}
+
+static int sync_all(trew_hip_ctx *ctx) {
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    for (auto &s : ctx->slots) HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    return 0;
+}
+
+extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows, uint64_t cap, uint64_t *n_rows) {
+    if (!ctx || !n_rows) return -1;
+    if (table < -1 || table >= TREW_NUM_TABLES) return fail(ctx, "table out of range");
+    if (int rc = sync_all(ctx)) return rc;
+    u32 ovf = 0;
+    HIPCHK(ctx, hipMemcpy(&ovf, ctx->table.overflow, 4, hipMemcpyDeviceToHost));
+    if (ovf) return fail(ctx, "device count table overflow: raise table_log2_slots");
+    std::vector<u64> keys(ctx->table_slots), counts(ctx->table_slots);
+    HIPCHK(ctx, hipMemcpy(keys.data(), ctx->table.keys, ctx->table_slots * 8, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(counts.data(), ctx->table.counts, ctx->table_slots * 8, hipMemcpyDeviceToHost));
+    u64 n = 0;
+    const u32 lps = ctx->table.log2_part_slots;
+    for (u64 i = 0; i < ctx->table_slots; i++) {
+        const u64 key = keys[i];
+        if (!key) continue;
+        const int t = (int) ((key >> 60) & 7ull);
+        if (table >= 0 && t != table) continue;
+        if (n < cap && rows) {
+            rows[n].k = (int32_t) ((key >> 55) & 31ull) + 1;
+            rows[n].table = t;
+            rows[n].word_lo = ((key & ((1ull << 55) - 1ull)) << kTablePartBits) | (i >> lps);
+            rows[n].word_hi = 0;
+            rows[n].count = counts[i];
+        }
+        n++;
+    }
+    *n_rows = n;
+    return 0;
+}
+
+extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
+    if (!ctx) return -1;
+    if (int rc = sync_all(ctx)) return rc;
+    HIPCHK(ctx, hipMemset(ctx->table.keys, 0, ctx->table_slots * 8));
+    HIPCHK(ctx, hipMemset(ctx->table.counts, 0, ctx->table_slots * 8));
+    HIPCHK(ctx, hipMemset(ctx->table.overflow, 0, 4));
+    return 0;
+}
+
+extern "C" int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_rows) {
+    if (!ctx) return -1;
+    if (n_rows == 0) return 0;
+    if (int rc = sync_all(ctx)) return rc;
+    for (u64 i = 0; i < n_rows; i++)
+        if (rows[i].k < 1 || rows[i].k > 32 || rows[i].table < 0 || rows[i].table >= TREW_NUM_TABLES || rows[i].word_hi)
+            return fail(ctx, "trew_hip_add_rows: row out of range");
+    trew_hip_row *d = nullptr;
+    HIPCHK(ctx, hipMalloc((void **) &d, n_rows * sizeof(trew_hip_row)));
+    hipError_t e = hipMemcpy(d, rows, n_rows * sizeof(trew_hip_row), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_add_rows(ctx->slots[0].stream, ctx->table, d, n_rows);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
+    (void) hipFree(d);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+extern "C" int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,
+                                        uint64_t *seq_high, uint64_t *seq_low, uint64_t n_reads) {
+    if (!ctx) return -1;
+    if (ctx->p.mode != TREW_MODE_SEGMENT) return fail(ctx, "segment results exist only in TREW_MODE_SEGMENT");
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    if (int rc = trew_hip_wait(ctx, slot)) return rc;
+    Slot &s = ctx->slots[(size_t) slot];
+    if (n_reads > s.n_units) return fail(ctx, "n_reads exceeds the last batch");
+    if (k_high) HIPCHK(ctx, hipMemcpy(k_high, s.res.k_high, n_reads * 4, hipMemcpyDeviceToHost));
+    if (k_low) HIPCHK(ctx, hipMemcpy(k_low, s.res.k_low, n_reads * 4, hipMemcpyDeviceToHost));
+    if (seq_high) HIPCHK(ctx, hipMemcpy(seq_high, s.res.seq_high, n_reads * 8, hipMemcpyDeviceToHost));
+    if (seq_low) HIPCHK(ctx, hipMemcpy(seq_low, s.res.seq_low, n_reads * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *batch, uint64_t *cand, int slots_per_read) {
+    if (!ctx || !batch || !cand) return -1;
+    if (slots_per_read < 1 || slots_per_read > kMaxSlots) return fail(ctx, "slots_per_read out of range");
+    if (int rc = sync_all(ctx)) return rc;
+    Slot &s = ctx->slots[0];
+    u32 max_seg = 0;
+    if (int rc = batch_geometry(ctx, batch, &max_seg)) return rc;
+    DevBatch db;
+    if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
+    if (db.n_units == 0) return 0;
+    u64 *d = nullptr;
+    const u64 bytes = db.n_units * (u64) slots_per_read * 8ull;
+    HIPCHK(ctx, hipMalloc((void **) &d, bytes));
+    hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 4, s.stream);
+    if (e == hipSuccess)
+        e = launch_filter(s.stream, pick_nw(max_seg), ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
+    if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+    if (e == hipSuccess) e = hipMemcpy(cand, d, bytes, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
+extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filter, float *ms_exact, uint64_t *n_flagged) {
+    if (!ctx) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    if (int rc = trew_hip_wait(ctx, slot)) return rc;
+    Slot &s = ctx->slots[(size_t) slot];
+    if (!s.timed) return fail(ctx, "no timed submit on this slot");
+    if (ms_filter) HIPCHK(ctx, hipEventElapsedTime(ms_filter, s.e0, s.e1));
+    if (ms_exact) HIPCHK(ctx, hipEventElapsedTime(ms_exact, s.e1, s.e2));
+    if (n_flagged) {
+        u32 c = 0;
+        HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count, 4, hipMemcpyDeviceToHost));
+        *n_flagged = c;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- host packing
+extern "C" uint64_t trew_pack_words(uint64_t n_bases) { return 3ull * ((n_bases + 31ull) / 32ull); }
+
+extern "C" uint64_t trew_pack_reads(const char *buf, const int64_t *st, const int64_t *nd, uint64_t n_reads,
+                                    uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths) {
+    // codes[], kmer.cpp:14-31: T=0 G=1 C=2 A=3, either case; everything else is "N"
+    static unsigned char lut[256];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 256; i++) lut[i] = 4;
+        lut[(int) 'T'] = lut[(int) 't'] = 0;
+        lut[(int) 'G'] = lut[(int) 'g'] = 1;
+        lut[(int) 'C'] = lut[(int) 'c'] = 2;
+        lut[(int) 'A'] = lut[(int) 'a'] = 3;
+        init = true;
+    }
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const int64_t n = nd[r] - st[r] + 1;
+        const uint64_t len = n > 0 ? (uint64_t) n : 0;
+        const uint64_t nw = (len + 31) / 32;
+        if (w + 3 * nw > words_cap || w > 0xffffffffull) return (uint64_t) -1;
+        offsets[r] = (uint32_t) w;
+        lengths[r] = (uint32_t) len;
+        const unsigned char *p = (const unsigned char *) buf + st[r];
+        for (uint64_t j = 0; j < nw; j++) {
+            uint32_t lo = 0, hi = 0, nm = 0;
+            const uint64_t m = std::min<uint64_t>(32, len - 32 * j);
+            for (uint64_t i = 0; i < m; i++) {
+                const unsigned c = lut[p[32 * j + i]];
+                lo |= (uint32_t) (c & 1u) << i;
+                hi |= (uint32_t) ((c >> 1) & 1u) << i;
+                nm |= (uint32_t) (c >> 2) << i;
+            }
+            lo &= ~nm;
+            hi &= ~nm;
+            words[w++] = lo;
+            words[w++] = hi;
+            words[w++] = nm;
+        }
+    }
+    return w;
+}
+
+// ---------------------------------------------------------------- synthetic workloads
+extern "C" int trew_synth_short_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, char *out) {
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const trew_synth::ReadClass c = trew_synth::read_class(seed, first_read + r);
+        char *o = out + r * (uint64_t) (read_len + 1);
+        for (uint32_t p = 0; p < read_len; p++) o[p] = trew_synth::base_char(trew_synth::short_base(seed, first_read + r, c, p, read_len));
+        o[read_len] = '\n';
+    }
+    return 0;
+}
+
+extern "C" int trew_synth_pair_ascii(uint64_t seed, uint64_t first_pair, uint64_t n_pairs, uint32_t read_len, char *out1, char *out2) {
+    for (uint64_t r = 0; r < n_pairs; r++) {
+        const trew_synth::ReadClass c = trew_synth::read_class(seed, first_pair + r);
+        char *o1 = out1 + r * (uint64_t) (read_len + 1);
+        char *o2 = out2 + r * (uint64_t) (read_len + 1);
+        for (uint32_t p = 0; p < read_len; p++) {
+            o1[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 0, p, read_len));
+            o2[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 1, p, read_len));
+        }
+        o1[read_len] = '\n';
+        o2[read_len] = '\n';
+    }
+    return 0;
+}
+
+extern "C" int trew_synth_short_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                       uint32_t read_len, uint32_t *d_words) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, launch_synth_short(ctx->slots[0].stream, seed, first_read, n_reads, read_len, d_words));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->slots[0].stream));
+    return 0;
+}
+
+extern "C" int trew_synth_pair_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                                      uint32_t read_len, uint32_t *d_words) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, launch_synth_pair(ctx->slots[0].stream, seed, first_pair, n_pairs, read_len, d_words));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->slots[0].stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- device memory helpers
+extern "C" int trew_hip_malloc(trew_hip_ctx *ctx, uint64_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, hipMalloc(d_ptr, bytes));
+    return 0;
+}
+extern "C" int trew_hip_free(trew_hip_ctx *ctx, void *d_ptr) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, hipFree(d_ptr));
+    return 0;
+}
+extern "C" int trew_hip_memcpy_h2d(trew_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int trew_hip_memcpy_d2h(trew_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    HIPCHK(ctx, hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}

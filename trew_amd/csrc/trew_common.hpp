@@ -1,0 +1,178 @@
+// trew_common.hpp -- types shared by the HIP kernels and the C-ABI host layer.
+//
+// MI355X-native restatement of the hot path of Chemical118/TREW src/kmer.cpp.
+// Nothing here is derived from the reference's data structures: per-thread
+// direct-address counters / hash maps (ThreadData, kmer.h:132-154) are replaced
+// by registers and LDS, the six ResultMaps (kmer.h:79-81) by one device-resident
+// open-addressing table with 64-bit CAS keys.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/trew_hip.h"
+
+namespace trew {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int kMaxSlots = 6;        // segments per unit: short 3, pair 6, long 2, segment 1
+constexpr int kMaxSegBases = 1023;  // longest segment any kernel accepts (short mode rejects reads > 1000, kmer.cpp:1006-1009)
+constexpr int kTablePartBits = 9;   // low word bits that select the table partition (see table_add)
+
+struct DevParams {
+    int min_mer, max_mer;
+    double low, high;
+    float lowf;  // conservative float lower bound of `low` used by the prefilter
+    int slice_len;
+    int mode;
+    u32 flags;
+};
+
+struct DevBatch {
+    const u32 *words;
+    const u32 *offsets;  // nullable
+    const u32 *lengths;  // nullable
+    u32 uniform_length;
+    u32 uniform_stride;
+    u64 n_reads;
+    u64 n_units;  // reads, or pairs in pair mode
+};
+
+// one unit (read / pair) that survived the prefilter, with the candidate-k mask
+// of each of its segments: bit (k-1) set <=> k may reach the low baseline.
+struct WorkItem {
+    u32 unit;
+    u32 pad;
+    u64 cand[kMaxSlots];
+};
+
+struct DevTable {
+    u64 *keys;    // 0 = empty
+    u64 *counts;
+    u32 log2_part_slots;  // slots per partition = 1 << log2_part_slots; 512 partitions
+    u32 *overflow;
+};
+
+// per-read outputs of TREW_MODE_SEGMENT
+struct SegResults {
+    int32_t *k_high;
+    int32_t *k_low;
+    u64 *seq_high;
+    u64 *seq_low;
+};
+
+struct Segment {
+    u32 mate;   // 0 = first read of the unit, 1 = second (pair mode)
+    u32 start;  // first base
+    u32 len;    // bases
+    int kmin, kmax;
+    bool valid;
+};
+
+#if defined(__HIPCC__)
+#define TREW_HD __host__ __device__
+#else
+#define TREW_HD
+#endif
+
+// Segment geometry of every per-read driver of the reference, as a pure
+// function of the read length(s).  slot numbering:
+//   short  (buffer_task, kmer.cpp:115-171):       0 left half, 1 right half, 2 whole read
+//   pair   (buffer_task_pair, kmer.cpp:333-340, 467-480): 0 R1-left 1 R1-right 2 R2-right 3 R2-left 4 R1 whole 5 R2 whole
+//   long   (buffer_task_long, kmer.cpp:790-798, 836-838): 0 first slice, 1 last slice (interior slices on demand)
+//   segment (k_mer_check, kmer.h:232):            0 whole read
+TREW_HD inline Segment get_segment(int mode, int slot, u32 n1, u32 n2, int MIN_MER, int MAX_MER, int SLICE) {
+    Segment s;
+    s.mate = 0;
+    s.start = 0;
+    s.len = 0;
+    s.kmin = 1;
+    s.kmax = 0;
+    s.valid = false;
+    auto imin = [](int a, int b) { return a < b ? a : b; };
+    auto imax = [](int a, int b) { return a > b ? a : b; };
+    if (mode == TREW_MODE_SHORT) {
+        int n = (int) n1;
+        if (2 * MIN_MER > n) return s;
+        if (slot <= 1) {
+            if (4 * MIN_MER > n) return s;
+            s.kmin = MIN_MER;
+            s.kmax = imin(n / 4, MAX_MER);
+            if (slot == 0) {
+                s.start = 0;
+                s.len = (u32) (n / 2);
+            } else {
+                s.start = (u32) (n - (n + 1) / 2);
+                s.len = (u32) ((n + 1) / 2);
+            }
+            s.valid = true;
+        } else if (slot == 2) {
+            if (4 * MAX_MER <= n) return s;
+            s.kmin = imax(n / 4 + 1, MIN_MER);
+            s.kmax = imin(n / 2, MAX_MER);
+            s.start = 0;
+            s.len = (u32) n;
+            s.valid = s.kmin <= s.kmax;
+        }
+    } else if (mode == TREW_MODE_PAIR) {
+        int a = (int) n1, b = (int) n2;
+        int n = imin(a, b);
+        if (2 * MIN_MER > n) return s;
+        if (slot <= 3) {
+            if (4 * MIN_MER > n) return s;
+            s.kmin = MIN_MER;
+            s.kmax = imin(n / 4, MAX_MER);
+            if (slot == 0) {
+                s.mate = 0; s.start = 0; s.len = (u32) (a / 2);
+            } else if (slot == 1) {
+                s.mate = 0; s.start = (u32) (a - (a + 1) / 2); s.len = (u32) ((a + 1) / 2);
+            } else if (slot == 2) {
+                s.mate = 1; s.start = (u32) (b - (b + 1) / 2); s.len = (u32) ((b + 1) / 2);
+            } else {
+                s.mate = 1; s.start = 0; s.len = (u32) (b / 2);
+            }
+            s.valid = true;
+        } else if (slot <= 5) {
+            if (4 * MAX_MER <= n) return s;
+            s.kmin = imax(n / 4 + 1, MIN_MER);
+            s.kmax = imin(n / 2, MAX_MER);
+            s.mate = (u32) (slot - 4);
+            s.start = 0;
+            s.len = slot == 4 ? (u32) a : (u32) b;
+            s.valid = s.kmin <= s.kmax;
+        }
+    } else if (mode == TREW_MODE_LONG) {
+        int len = (int) n1;
+        int snum = len / SLICE;
+        if (snum == 0 || slot > 1) return s;
+        int mid = (snum + 1) / 2;
+        int bonus = len % SLICE;
+        s.kmin = MIN_MER;
+        s.kmax = MAX_MER;
+        if (slot == 0) {
+            s.start = 0;
+            s.len = (u32) (SLICE + (1 == mid ? bonus : 0));
+        } else {
+            int sl = SLICE + (snum == mid ? bonus : 0);
+            s.start = (u32) (len - sl);
+            s.len = (u32) sl;
+        }
+        s.valid = true;
+    } else {  // TREW_MODE_SEGMENT
+        if (slot != 0 || n1 == 0) return s;
+        s.kmin = MIN_MER;
+        s.kmax = MAX_MER;
+        s.start = 0;
+        s.len = n1;
+        s.valid = true;
+    }
+    return s;
+}
+
+TREW_HD inline int mode_slots(int mode) {
+    return mode == TREW_MODE_SHORT ? 3 : mode == TREW_MODE_PAIR ? 6 : mode == TREW_MODE_LONG ? 2 : 1;
+}
+
+// launchers implemented in trew_kernels.hip
+struct LaunchTiming;
+}  // namespace trew

@@ -1,0 +1,763 @@
+// trew_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the TREW tandem-repeat scan.
+//
+// Two kernels per batch, both pure integer (no MFMA -- this is bit/byte work):
+//
+//  1. filter_kernel<NW>  one LANE per read.  Bit-parallel, branch-free upper
+//     bound on max-class/COUNT for every k in [MIN_MER, MAX_MER] of every
+//     segment of the read.  Windows in one rotation class (get_rot_seq,
+//     kmer.cpp:1815-1823) have the same base composition, hence the same three
+//     parities (#lo-bit, #hi-bit, #A mod 2).  Those parities for ALL windows of
+//     one k are three XORs of a prefix-parity mask with itself shifted by k, so
+//     the 8 bucket sizes are 8 popcounts and max-bucket >= MAX (kmer.cpp:2202).
+//     A (segment,k) whose bound is below LOW_BASELINE*COUNT can never be
+//     accepted by the selection loops (kmer.cpp:2221-2258); everything else is
+//     a "candidate".  Reads with no candidate (~98.5 % of WGS-like input) are
+//     finished here.  The bound is sound by construction: it never drops a k.
+//
+//  2. exact_kernel       one WAVEFRONT (64 lanes) per surviving read.  Restates
+//     k_mer_check / k_mer_target / buffer_task* exactly, but only for candidate
+//     k: lanes own windows, canonical rotations go to LDS, class sizes come
+//     from an all-pairs LDS-broadcast compare, MAX_SEQ's "first class to reach
+//     the maximum" tie-break (strict '<' at kmer.cpp:2202) is the class whose
+//     last window comes first.  Histograms are added to a device-resident
+//     open-addressing table with 64-bit CAS keys.
+//
+// No CUDA shims, no dual paths: HIP for gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include "trew_common.hpp"
+#include "trew_launch.hpp"
+#include "trew_synth.hpp"
+
+namespace trew {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) {
+    return __builtin_amdgcn_alignbit(hi, lo, sh);  // ((hi:lo) >> (sh & 31)) & 0xffffffff
+}
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ u64 rfl64(u64 v) {
+    u32 lo = __builtin_amdgcn_readfirstlane((u32) v);
+    u32 hi = __builtin_amdgcn_readfirstlane((u32) (v >> 32));
+    return ((u64) hi << 32) | lo;
+}
+
+struct ReadRef {
+    const u32 *w;  // first triple
+    u32 len;       // bases
+    u32 nw;        // triples
+};
+
+__device__ __forceinline__ ReadRef get_read(const DevBatch &b, u64 r) {
+    ReadRef x;
+    u64 off = b.offsets ? (u64) b.offsets[r] : r * (u64) b.uniform_stride;
+    x.len = b.lengths ? b.lengths[r] : b.uniform_length;
+    x.w = b.words + off;
+    x.nw = (x.len + 31u) >> 5;
+    return x;
+}
+
+// 32*NW plane bits starting at base s of a read: lo/hi/nmask, bit i = base s+i.
+template <int NW>
+__device__ __forceinline__ void load_planes(const ReadRef &rd, u32 s, u32 (&lo)[NW], u32 (&hi)[NW], u32 (&nm)[NW]) {
+    const u32 ws = s >> 5, bs = s & 31u;
+    u32 c0 = 0, c1 = 0, c2 = 0;
+    if (ws < rd.nw) {
+        c0 = rd.w[3 * ws + 0];
+        c1 = rd.w[3 * ws + 1];
+        c2 = rd.w[3 * ws + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        u32 n0 = 0, n1 = 0, n2 = 0;
+        const u32 idx = ws + (u32) j + 1u;
+        if (idx < rd.nw) {
+            n0 = rd.w[3 * idx + 0];
+            n1 = rd.w[3 * idx + 1];
+            n2 = rd.w[3 * idx + 2];
+        }
+        lo[j] = alignbit(n0, c0, bs);
+        hi[j] = alignbit(n1, c1, bs);
+        nm[j] = alignbit(n2, c2, bs);
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+    }
+}
+
+// ------------------------------------------------------------------ prefilter
+template <int NW>
+__device__ __forceinline__ void shr1(u32 (&x)[NW]) {
+#pragma unroll
+    for (int j = 0; j < NW - 1; j++) x[j] = alignbit(x[j + 1], x[j], 1);
+    x[NW - 1] >>= 1;
+}
+
+// exclusive prefix parity of f over bits 0..32*NW-1: P[i] = XOR_{t<i} f[t]
+template <int NW>
+__device__ __forceinline__ void prefix_parity(const u32 (&f)[NW], u32 (&P)[NW]) {
+    u32 carry = 0, prev_top = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        u32 x = f[j];
+        x ^= x << 1;
+        x ^= x << 2;
+        x ^= x << 4;
+        x ^= x << 8;
+        x ^= x << 16;
+        x ^= carry;  // carry = all-ones when the parity of all lower words is odd
+        P[j] = (x << 1) | prev_top;
+        prev_top = x >> 31;
+        carry = 0u - prev_top;
+    }
+}
+
+// Candidate-k mask of one segment (bit k-1).  lo/hi/nm hold the segment's
+// planes from bit 0; L <= 32*NW-1 bases.  gmin..gmax is the wave-uniform k
+// loop (MIN_MER..MAX_MER); only k in [kmin,kmax] can become candidates.
+template <int NW>
+__device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&hi)[NW], const u32 (&nm)[NW], int L,
+                                              int kmin, int kmax, int gmin, int gmax, float lowf) {
+    u32 v1[NW], P1[NW], P2[NW], P3[NW];
+    {
+        u32 f1[NW], f2[NW], f3[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            int bits = L - 32 * j;
+            u32 lm = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+            v1[j] = ~nm[j] & lm;  // base is A/C/G/T and inside the segment
+            f1[j] = lo[j] & v1[j];
+            f2[j] = hi[j] & v1[j];
+            f3[j] = f1[j] & f2[j];
+        }
+        prefix_parity<NW>(f1, P1);
+        prefix_parity<NW>(f2, P2);
+        prefix_parity<NW>(f3, P3);
+    }
+    u32 V[NW], SV[NW], S1[NW], S2[NW], S3[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        V[j] = v1[j];
+        SV[j] = v1[j];
+        S1[j] = P1[j];
+        S2[j] = P2[j];
+        S3[j] = P3[j];
+    }
+    // advance to k = gmin:  V = V_gmin (windows with no N, kmer.cpp:2190), S = P >> gmin
+    for (int t = 1; t < gmin; t++) {
+        shr1<NW>(SV);
+#pragma unroll
+        for (int j = 0; j < NW; j++) V[j] &= SV[j];
+    }
+    for (int t = 0; t < gmin; t++) {
+        shr1<NW>(S1);
+        shr1<NW>(S2);
+        shr1<NW>(S3);
+    }
+    u64 cand = 0;
+    for (int k = gmin; k <= gmax; k++) {
+        u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0, count = 0;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const u32 F1 = P1[j] ^ S1[j], F2 = P2[j] ^ S2[j], F3 = P3[j] ^ S3[j];
+            const u32 v = V[j];
+            const u32 a1 = v & F1, a0 = v ^ a1;
+            const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
+            const u32 b111 = a11 & F3, b110 = a11 ^ b111, b101 = a10 & F3, b100 = a10 ^ b101;
+            const u32 b011 = a01 & F3, b010 = a01 ^ b011, b001 = a00 & F3, b000 = a00 ^ b001;
+            count += __popc(v);
+            c000 += __popc(b000);
+            c001 += __popc(b001);
+            c010 += __popc(b010);
+            c011 += __popc(b011);
+            c100 += __popc(b100);
+            c101 += __popc(b101);
+            c110 += __popc(b110);
+            c111 += __popc(b111);
+        }
+        const u32 m = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
+        // sound: MAX <= m, so MAX/COUNT >= LOW needs m >= LOW*COUNT; lowf < LOW*(1-1e-6) absorbs float rounding
+        const bool pass = count != 0u && (float) m >= (float) count * lowf && k >= kmin && k <= kmax;
+        cand |= pass ? (1ull << (k - 1)) : 0ull;
+        shr1<NW>(SV);
+#pragma unroll
+        for (int j = 0; j < NW; j++) V[j] &= SV[j];
+        shr1<NW>(S1);
+        shr1<NW>(S2);
+        shr1<NW>(S3);
+    }
+    return cand;
+}
+
+__device__ __forceinline__ u64 all_k_mask(int kmin, int kmax) {
+    if (kmax < kmin) return 0;
+    u64 hi = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+    u64 lo = (1ull << (kmin - 1)) - 1ull;
+    return hi & ~lo;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, WorkItem *wl, u32 *wl_count, u32 wl_cap,
+                                                     u64 *dbg_masks, int dbg_slots) {
+    const u64 unit = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = unit < B.n_units;
+    ReadRef rd[2];
+    rd[0].w = B.words;
+    rd[0].len = 0;
+    rd[0].nw = 0;
+    rd[1] = rd[0];
+    if (active) {
+        if (P.mode == TREW_MODE_PAIR) {
+            rd[0] = get_read(B, 2 * unit);
+            rd[1] = get_read(B, 2 * unit + 1);
+        } else {
+            rd[0] = get_read(B, unit);
+        }
+    }
+    u64 masks[kMaxSlots];
+    const int nslots = mode_slots(P.mode);
+    u64 any = 0;
+#pragma unroll
+    for (int slot = 0; slot < kMaxSlots; slot++) {
+        masks[slot] = 0;
+        if (slot < nslots) {
+            Segment sg = get_segment(P.mode, slot, rd[0].len, rd[1].len, P.min_mer, P.max_mer, P.slice_len);
+            const bool ok = active && sg.valid && sg.len <= (u32) (32 * NW - 1);
+            if (__any(ok)) {
+                u32 lo[NW], hi[NW], nm[NW];
+                const ReadRef &r = sg.mate ? rd[1] : rd[0];
+                if (ok) {
+                    load_planes<NW>(r, sg.start, lo, hi, nm);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NW; j++) {
+                        lo[j] = hi[j] = 0;
+                        nm[j] = 0xffffffffu;
+                    }
+                }
+                u64 m;
+                if (P.flags & TREW_FLAG_NO_FILTER)
+                    m = all_k_mask(sg.kmin, sg.kmax);
+                else
+                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer, P.max_mer, P.lowf);
+                masks[slot] = ok ? m : 0ull;
+            }
+            // a segment too long for this instantiation must never be dropped silently
+            if (active && sg.valid && sg.len > (u32) (32 * NW - 1)) masks[slot] = all_k_mask(sg.kmin, sg.kmax);
+            any |= masks[slot];
+            if (dbg_masks && active && slot < dbg_slots) dbg_masks[unit * (u64) dbg_slots + slot] = masks[slot];
+        }
+    }
+    // wave-aggregated append to the worklist
+    const bool flag = active && any != 0;
+    const u64 bal = __ballot(flag);
+    if (bal) {
+        const u32 lane = lane_id();
+        u32 base = 0;
+        if (lane == (u32) __ffsll((long long) bal) - 1u) base = atomicAdd(wl_count, (u32) __popcll(bal));
+        base = __shfl(base, __ffsll((long long) bal) - 1);
+        if (flag) {
+            const u32 rank = (u32) __popcll(bal & ((1ull << lane) - 1ull));
+            const u32 idx = base + rank;
+            if (idx < wl_cap) {
+                WorkItem it;
+                it.unit = (u32) unit;
+                it.pad = 0;
+#pragma unroll
+                for (int s = 0; s < kMaxSlots; s++) it.cand[s] = masks[s];
+                wl[idx] = it;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ count table
+// Key layout (64 bits, one CAS claims a slot, lock-free and exact):
+//   bit 63 valid | bits 62..60 table | bits 59..55 k-1 | bits 54..0 word >> 9
+// The 9 low bits of the word select one of 512 partitions, so the full 2k-bit
+// word (up to 64 bits at k = 32) is recoverable as (stored << 9) | partition.
+__device__ __forceinline__ u64 hash64(u64 x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ void table_add(const DevTable &T, int table, int k, u64 word, u64 cnt) {
+    const u32 part = (u32) (word & ((1u << kTablePartBits) - 1u));
+    const u64 key = (1ull << 63) | ((u64) table << 60) | ((u64) (k - 1) << 55) | (word >> kTablePartBits);
+    const u32 S = 1u << T.log2_part_slots, mask = S - 1u;
+    const u32 h = (u32) hash64(key) & mask;
+    const u64 base = (u64) part << T.log2_part_slots;
+    for (u32 probe = 0; probe < S; probe++) {
+        const u64 idx = base + ((h + probe) & mask);
+        u64 cur = __hip_atomic_load(&T.keys[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0) {
+            u64 expected = 0;
+            if (__hip_atomic_compare_exchange_strong(&T.keys[idx], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT))
+                cur = key;
+            else
+                cur = expected;
+        }
+        if (cur == key) {
+            __hip_atomic_fetch_add(&T.counts[idx], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    atomicExch(T.overflow, 1u);
+}
+
+// ------------------------------------------------------------------ exact path
+constexpr int kSegWords = (kMaxSegBases + 1) / 32;  // 32
+
+struct __attribute__((aligned(16))) ExactSmem {
+    u64 seq[kSegWords + 2];    // 2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
+    u32 nmask[kSegWords + 2];  // bit i = base i is not A/C/G/T or lies past the segment end
+    u64 canon[kMaxSegBases + 1];
+    u64 vmask[(kMaxSegBases + 64) / 64];
+    unsigned short cnt[kMaxSegBases + 1];  // class size at the class's first window, else 0
+};
+
+__device__ __forceinline__ u64 spread32(u32 v) {
+    u64 x = v;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+// stage bases [s, s+L) of a read into LDS (one wave)
+__device__ void load_segment(ExactSmem &sm, const ReadRef &rd, u32 s, u32 L) {
+    const u32 lane = lane_id();
+    const u32 nwords = (L + 31u) >> 5;
+    if (lane < kSegWords + 2) {
+        u64 sq = 0;
+        u32 nmv = 0xffffffffu;
+        if (lane < nwords) {
+            u32 lo[1], hi[1], nm[1];
+            load_planes<1>(rd, s + 32u * lane, lo, hi, nm);
+            const int bits = (int) L - 32 * (int) lane;
+            const u32 lm = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+            nmv = nm[0] | ~lm;
+            const u32 l = lo[0] & ~nmv, h = hi[0] & ~nmv;
+            sq = spread32(__brev(l)) | (spread32(__brev(h)) << 1);
+        }
+        sm.seq[lane] = sq;
+        sm.nmask[lane] = nmv;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ u64 kmask(int k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull); }
+
+// get_rot_seq, kmer.cpp:1815-1823
+__device__ __forceinline__ u64 min_rotation(u64 w, int k) {
+    u64 tmp = w, ans = w;
+    const int sh = 2 * (k - 1);
+    for (int i = 0; i < k - 1; i++) {
+        tmp = ((tmp & 3ull) << sh) | (tmp >> 2);
+        ans = tmp < ans ? tmp : ans;
+    }
+    return ans;
+}
+// reverse_complement_64(x) >> 2*(32-k), kmer.cpp:47-54 / 1987
+__device__ __forceinline__ u64 revcomp(u64 x, int k) {
+    x = (x >> 32) | (x << 32);
+    x = ((x >> 16) & 0x0000ffff0000ffffull) | ((x & 0x0000ffff0000ffffull) << 16);
+    x = ((x >> 8) & 0x00ff00ff00ff00ffull) | ((x & 0x00ff00ff00ff00ffull) << 8);
+    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    return (~x) >> (2 * (32 - k));
+}
+// get_repeat_check, kmer.cpp:1835-1850: the word uses a single base
+__device__ __forceinline__ bool is_homopolymer(u64 w, int k) {
+    return w == ((w & 3ull) * (0x5555555555555555ull & kmask(k)));
+}
+
+struct KStat {
+    u32 count;  // K_MER_DATA_COUNT
+    u32 maxc;   // K_MER_DATA_MAX
+    u64 maxseq; // K_MER_DATA_MAX_SEQ
+};
+
+// One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
+// 1936-1967) on the segment staged in sm.  Leaves canon[] / vmask[] / cnt[] in
+// LDS for emit_k.  All lanes must call it; the result is wave-uniform.
+__device__ KStat eval_k(ExactSmem &sm, int L, int k) {
+    KStat st;
+    st.count = 0;
+    st.maxc = 0;
+    st.maxseq = 0;
+    const int W = L - k + 1;
+    if (W <= 0) return st;
+    const u32 lane = lane_id();
+    const int rounds = (W + 63) >> 6;
+    __syncthreads();  // previous users of canon/cnt are done
+    for (int r = 0; r < rounds; r++) {
+        const int i = r * 64 + (int) lane;
+        bool valid = false;
+        u64 c = 0;
+        if (i < W) {
+            const u32 wi = (u32) i >> 5, bi = (u32) i & 31u;
+            const u64 nmw = (((u64) sm.nmask[wi + 1] << 32) | sm.nmask[wi]) >> bi;
+            valid = (nmw & ((1ull << k) - 1ull)) == 0;  // no N inside the window (kmer.cpp:2190)
+            if (valid) {
+                const u64 a = sm.seq[wi], b = sm.seq[wi + 1];
+                const u32 sh = 2u * bi;
+                const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
+                c = min_rotation(x >> (64 - 2 * k), k);
+            }
+            sm.canon[i] = c;
+            sm.cnt[i] = 0;
+        }
+        const u64 bal = __ballot(valid);
+        if (lane == 0) sm.vmask[r] = bal;
+    }
+    __syncthreads();
+    u32 best = 0;  // (class size << 16) | (0xffff - last window of the class)
+    u64 best_seq = 0;
+    for (int r = 0; r < rounds; r++) {
+        const int i = r * 64 + (int) lane;
+        const bool mine = i < W && ((sm.vmask[r] >> lane) & 1ull);
+        const u64 my = mine ? sm.canon[i] : 0;
+        u32 c = 0, last = 0;
+        bool first = true;
+        for (int jr = 0; jr < rounds; jr++) {
+            u64 vm = rfl64(sm.vmask[jr]);
+            st.count += r == 0 ? (u32) __popcll(vm) : 0u;
+            while (vm) {
+                const int jb = __ffsll((long long) vm) - 1;
+                vm &= vm - 1;
+                const int j = jr * 64 + jb;
+                const bool eq = sm.canon[j] == my;  // LDS broadcast read
+                c += eq ? 1u : 0u;
+                last = eq ? (u32) j : last;
+                first = first && !(eq && j < i);
+            }
+        }
+        if (mine) {
+            if (first) sm.cnt[i] = (unsigned short) c;
+            const u32 key = (c << 16) | (0xffffu - last);
+            if (key > best) {
+                best = key;
+                best_seq = my;
+            }
+        }
+    }
+    // wave argmax: largest class, ties to the class whose last window is earliest
+    // (the first to reach the maximum in scan order, strict '<' at kmer.cpp:2202)
+    u32 m = best;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (u32) __shfl_xor((int) m, off));
+    const u64 who = __ballot(best == m && m != 0);
+    if (who) {
+        const int src = __ffsll((long long) who) - 1;
+        st.maxc = m >> 16;
+        st.maxseq = ((u64) (u32) __shfl((int) (best_seq >> 32), src) << 32) | (u32) __shfl((int) (u32) best_seq, src);
+    }
+    st.count = rfl(st.count);
+    __syncthreads();
+    return st;
+}
+
+// add every class of the k just evaluated to the tables in table_mask (bit t).
+// strand_canon: key = MIN(w, rot(rc(w))) (k_mer_target, kmer.cpp:1979-1988) else the
+// rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
+__device__ void emit_k(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
+    const int W = L - k + 1;
+    const u32 lane = lane_id();
+    for (int i = (int) lane; i < W; i += 64) {
+        const u32 c = sm.cnt[i];
+        if (c) {
+            u64 w = sm.canon[i];
+            if (strand_canon) {
+                const u64 rc = min_rotation(revcomp(w, k), k);
+                w = rc < w ? rc : w;
+            }
+            for (u32 tm = table_mask; tm; tm &= tm - 1) table_add(T, __ffs((int) tm) - 1, k, w, c);
+        }
+    }
+}
+
+struct Decision {
+    int kh, kl;   // target_k_high / target_k_low
+    u64 sh, sl;   // MAX_SEQ at those k (repeat_seq, kmer.cpp:2260-2262)
+};
+
+__device__ __forceinline__ bool divides_any(int k, u64 accepted) {
+    while (accepted) {
+        const int tk = __ffsll((long long) accepted);  // bit tk-1 -> k value tk
+        accepted &= accepted - 1;
+        if (k % tk == 0) return true;
+    }
+    return false;
+}
+
+// selection loops of k_mer_check, kmer.cpp:2221-2258, run online over ascending
+// candidate k (non-candidates have frequency < LOW and can never be accepted)
+__device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, int kmax, u64 cand) {
+    Decision d;
+    d.kh = d.kl = 0;
+    d.sh = d.sl = 0;
+    double tf_low = 0.0, tf_high = 0.0;
+    u64 acc_low = 0, acc_high = 0;
+    for (int k = kmin; k <= kmax; k++) {
+        if (!((cand >> (k - 1)) & 1ull)) continue;
+        const KStat st = eval_k(sm, L, k);
+        if (st.count == 0) continue;  // 0/0 = NaN fails every >=
+        const double f = (double) st.maxc / (double) st.count;
+        if (is_homopolymer(st.maxseq, k)) continue;
+        if (f >= (P.low > tf_low ? P.low : tf_low) && !divides_any(k, acc_low)) {
+            d.kl = k;
+            tf_low = f;
+            acc_low |= 1ull << (k - 1);
+            d.sl = st.maxseq;
+        }
+        if (f >= (P.high > tf_high ? P.high : tf_high) && !divides_any(k, acc_high)) {
+            d.kh = k;
+            tf_high = f;
+            acc_high |= 1ull << (k - 1);
+            d.sh = st.maxseq;
+        }
+    }
+    return d;
+}
+
+// record the histogram of segment (already staged) at k into tables
+__device__ void record(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
+    if (k <= 0 || table_mask == 0) return;
+    eval_k(sm, L, k);
+    emit_k(sm, T, L, k, table_mask, strand_canon);
+}
+
+// k_mer_target, kmer.cpp:1894-2017, on the staged whole read
+__device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
+    const KStat st = eval_k(sm, L, k);
+    if (st.count == 0) return;
+    const double f = is_homopolymer(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
+    u32 tm = 0;
+    if (want_high && f >= P.high) tm |= 1u << TREW_TABLE_BOTH_HIGH;
+    if (want_low && f >= P.low) tm |= 1u << TREW_TABLE_BOTH_LOW;
+    if (tm) emit_k(sm, T, L, k, tm, true);
+}
+
+// buffer_task, kmer.cpp:111-173
+__device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+    const ReadRef rd = get_read(B, it.unit);
+    const int n = (int) rd.len;
+    const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
+    const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
+    const Segment sW = get_segment(TREW_MODE_SHORT, 2, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
+    Decision left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
+    if (sL.valid) {
+        load_segment(sm, rd, sL.start, sL.len);
+        left = decide(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0]);
+        load_segment(sm, rd, sR.start, sR.len);
+        right = decide(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1]);
+        const bool left_found = left.kh > 0 || left.kl > 0;
+        const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
+        const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
+        // right half (staged): recorded only where the map passed was non-null
+        //  - left found nothing: result.backward directly (kmer.cpp:157-158)
+        //  - left found something: temp_result_right.b only when left.b == 0 (kmer.cpp:125), flushed to backward when no target
+        {
+            const bool rec_h = right.kh > 0 && (!left_found || (left.kh == 0));
+            const bool rec_l = right.kl > 0 && (!left_found || (left.kl == 0));
+            if (rec_h && rec_l && right.kh == right.kl) {
+                record(sm, T, (int) sR.len, right.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
+            } else {
+                if (rec_h) record(sm, T, (int) sR.len, right.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
+                if (rec_l) record(sm, T, (int) sR.len, right.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+            }
+        }
+        if (left_found) {
+            const bool rec_h = left.kh > 0 && !tgt_h;  // temp_result_left.first -> forward.first (kmer.cpp:132-134)
+            const bool rec_l = left.kl > 0 && !tgt_l;
+            if (rec_h || rec_l) {
+                load_segment(sm, rd, sL.start, sL.len);
+                if (rec_h && rec_l && left.kh == left.kl) {
+                    record(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
+                } else {
+                    if (rec_h) record(sm, T, (int) sL.len, left.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
+                    if (rec_l) record(sm, T, (int) sL.len, left.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
+                }
+            }
+            if (tgt_h || tgt_l) {
+                load_segment(sm, rd, 0, (u32) n);
+                if (tgt_h && tgt_l && left.kh == left.kl) {
+                    target(sm, P, T, n, left.kh, true, true);
+                } else {
+                    if (tgt_h) target(sm, P, T, n, left.kh, true, false);
+                    if (tgt_l) target(sm, P, T, n, left.kl, false, true);
+                }
+            }
+        }
+    }
+    const bool hh = left.kh == 0 && right.kh == 0;  // kmer.cpp:165-166
+    const bool lh = left.kl == 0 && right.kl == 0;
+    if (sW.valid && (hh || lh)) {  // kmer.cpp:168-171
+        load_segment(sm, rd, 0, (u32) n);
+        const Decision w = decide(sm, P, n, sW.kmin, sW.kmax, it.cand[2]);
+        const bool rec_h = hh && w.kh > 0, rec_l = lh && w.kl > 0;
+        if (rec_h && rec_l && w.kh == w.kl) {
+            record(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
+        } else {
+            if (rec_h) record(sm, T, n, w.kh, 1u << TREW_TABLE_BOTH_HIGH, false);
+            if (rec_l) record(sm, T, n, w.kl, 1u << TREW_TABLE_BOTH_LOW, false);
+        }
+    }
+}
+
+// TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
+__device__ void run_segment(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it,
+                            const SegResults &R) {
+    const ReadRef rd = get_read(B, it.unit);
+    const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
+    if (!s.valid) return;
+    load_segment(sm, rd, 0, s.len);
+    const Decision d = decide(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0]);
+    if (d.kh > 0 && d.kh == d.kl) {
+        record(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
+    } else {
+        record(sm, T, (int) s.len, d.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
+        record(sm, T, (int) s.len, d.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
+    }
+    if (lane_id() == 0 && R.k_high) {
+        R.k_high[it.unit] = d.kh;
+        R.k_low[it.unit] = d.kl;
+        R.seq_high[it.unit] = d.sh;
+        R.seq_low[it.unit] = d.sl;
+    }
+}
+
+__global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
+                                                   const u32 *wl_count, u32 wl_cap, SegResults R) {
+    __shared__ ExactSmem sm;
+    u32 n = *wl_count;
+    n = n < wl_cap ? n : wl_cap;
+    for (u32 w = blockIdx.x; w < n; w += gridDim.x) {
+        const WorkItem it = wl[w];
+        if (P.mode == TREW_MODE_SHORT)
+            run_short(sm, P, B, T, it);
+        else if (P.mode == TREW_MODE_SEGMENT)
+            run_segment(sm, P, B, T, it, R);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ table maintenance
+__global__ void table_add_rows_kernel(DevTable T, const trew_hip_row *rows, u64 n) {
+    const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table_add(T, rows[i].table, rows[i].k, rows[i].word_lo, rows[i].count);
+}
+
+// ------------------------------------------------------------------ synthetic generators
+__global__ void synth_short_kernel(u64 seed, u64 first_read, u64 n_reads, u32 read_len, u32 *words) {
+    const u32 nw = (read_len + 31u) >> 5;
+    const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads * nw) return;
+    const u64 r = t / nw;
+    const u32 j = (u32) (t % nw);
+    const trew_synth::ReadClass c = trew_synth::read_class(seed, first_read + r);
+    u32 lo = 0, hi = 0, nm = 0;
+    for (u32 i = 0; i < 32; i++) {
+        const u32 pos = 32u * j + i;
+        if (pos >= read_len) break;
+        const int b = trew_synth::short_base(seed, first_read + r, c, pos, read_len);
+        if (b > 3) {
+            nm |= 1u << i;
+        } else {
+            lo |= (u32) (b & 1) << i;
+            hi |= (u32) (b >> 1) << i;
+        }
+    }
+    u32 *o = words + (r * nw + j) * 3ull;
+    o[0] = lo;
+    o[1] = hi;
+    o[2] = nm;
+}
+
+__global__ void synth_pair_kernel(u64 seed, u64 first_pair, u64 n_pairs, u32 read_len, u32 *words) {
+    const u32 nw = (read_len + 31u) >> 5;
+    const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pairs * 2ull * nw) return;
+    const u64 rr = t / nw;  // read index: 2*pair + mate
+    const u32 j = (u32) (t % nw);
+    const u64 pair = rr >> 1;
+    const int mate = (int) (rr & 1ull);
+    const trew_synth::ReadClass c = trew_synth::read_class(seed, first_pair + pair);
+    u32 lo = 0, hi = 0, nm = 0;
+    for (u32 i = 0; i < 32; i++) {
+        const u32 pos = 32u * j + i;
+        if (pos >= read_len) break;
+        const int b = trew_synth::pair_base(seed, first_pair + pair, c, mate, pos, read_len);
+        if (b > 3) {
+            nm |= 1u << i;
+        } else {
+            lo |= (u32) (b & 1) << i;
+            hi |= (u32) (b >> 1) << i;
+        }
+    }
+    u32 *o = words + (rr * nw + j) * 3ull;
+    o[0] = lo;
+    o[1] = hi;
+    o[2] = nm;
+}
+
+// ------------------------------------------------------------------ launchers
+int pick_nw(u32 max_seg_len) {
+    if (max_seg_len <= 95) return 3;
+    if (max_seg_len <= 159) return 5;
+    if (max_seg_len <= 319) return 10;
+    return 32;
+}
+
+hipError_t launch_filter(hipStream_t st, int nw, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
+                         u32 wl_cap, u64 *dbg_masks, int dbg_slots) {
+    if (B.n_units == 0) return hipSuccess;
+    const u32 threads = 256;
+    const u64 blocks = (B.n_units + threads - 1) / threads;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    dim3 g((u32) blocks), b(threads);
+    switch (nw) {
+    case 3: hipLaunchKernelGGL(filter_kernel<3>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
+    case 5: hipLaunchKernelGGL(filter_kernel<5>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
+    case 10: hipLaunchKernelGGL(filter_kernel<10>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
+    default: hipLaunchKernelGGL(filter_kernel<32>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
+                        const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R) {
+    hipLaunchKernelGGL(exact_kernel, dim3(grid), dim3(64), 0, st, P, B, T, wl, wl_count, wl_cap, R);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(table_add_rows_kernel, dim3((u32) ((n + 255) / 256)), dim3(256), 0, st, T, d_rows, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words) {
+    const u64 total = n * ((len + 31u) >> 5);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_short_kernel, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, seed, first, n, len, d_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_pair(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words) {
+    const u64 total = n * 2ull * ((len + 31u) >> 5);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_pair_kernel, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, seed, first, n, len, d_words);
+    return hipGetLastError();
+}
+
+}  // namespace trew
