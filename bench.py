@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbases/s scanned, `short 5 32`, synthetic 150 bp reads, on N MI355X.
+
+Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W`;
+for N > 1 it is launched by torch.distributed.run, one rank per GPU.  A "step"
+is one pass of the hot path (prefilter kernel + exact kernel + count-table
+accumulation) over one batch of `--reads` synthetic reads that are already
+resident in HBM when the timed region starts.  Reads are sharded contiguously
+across ranks (weak scaling: every rank scans its own --reads reads); the only
+exchange is the final reduction of the count tables, which is inside the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 20250218
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# integer-issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one VALU lane-op per lane per clock)
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
+EVALS_PER_150BP_READ = 3220  # (window,k) evaluations per 150-bp read at 5 32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (config 2: 10M x 150 bp)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--min-mer", type=int, default=5)
+    ap.add_argument("--max-mer", type=int, default=32)
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import trew_amd as T
+    from trew_amd import capi
+    from trew_amd.dist import allreduce_tables
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    n, L = args.reads, args.read_len
+    stride = 3 * ((L + 31) // 32)
+    t = T.TrewHip(mode=T.MODE_SHORT, min_mer=args.min_mer, max_mer=args.max_mer, device=dev.index, n_slots=1,
+                  max_batch_words=16, max_batch_reads=n, table_log2_slots=20)
+    d_words = t.malloc(n * stride * 4 + 64)
+    first_read = rank * n  # contiguous read-index ranges per rank
+    t.synth_short_device(SEED, first_read, n, L, d_words)
+    batch = t.device_uniform_batch(d_words, n, L)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        t.submit(batch, 0)
+        t.wait(0)
+
+    for _ in range(args.warmup):
+        step()
+    t.reset_tables()
+    filt_ms, exact_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        a, b, nflag = t.last_timing(0)  # HIP events on the kernels' own stream
+        filt_ms.append(a)
+        exact_ms.append(b)
+    tables = t.collect()
+    merged = allreduce_tables(tables, device=dev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    bases = float(world) * n * L * args.steps
+    value = bases / dt / 1e9
+    ms_per_step = dt / args.steps * 1e3
+
+    out = None
+    if rank == 0:
+        f_avg = sum(filt_ms) / len(filt_ms)
+        e_avg = sum(exact_ms) / len(exact_ms)
+        dom, dom_ms = ("filter_kernel", f_avg) if f_avg >= e_avg else ("exact_kernel", e_avg)
+        # algorithmic bytes per launch: 0.25 B per base (2-bit input) + 8 B per read (offset/length), SURVEY 8(d)
+        alg_bytes = n * L * 0.25 + n * 8.0
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        evals = EVALS_PER_150BP_READ * (L / 150.0) * n
+        out = {
+            "metric": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
+            "value": round(value, 3),
+            "unit": "Gbases/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "short %d %d, %d synthetic %d bp reads per GPU (TTAGGG-seeded, seed %d)" % (
+                    args.min_mer, args.max_mer, n, L, SEED),
+                "reads_per_gpu": n,
+                "read_len": L,
+                "parallelism": "dp%d read-sharded, one table all-reduce" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
+                "note": "integer-issue bound, not HBM bound (SURVEY 8(d)): %.3g (window,k) evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
+                        % (evals / ((f_avg + e_avg) * 1e-3), evals / ((f_avg + e_avg) * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
+            },
+            "flagged_reads_per_step": int(nflag),
+            "table_rows": sum(len(v) for v in merged.values()),
+        }
+
+    # CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle as O
+
+        m = min(args.cpu_reads, n)
+        buf, st, nd = capi.synth_short_ascii(SEED, 0, m, L)
+        cores = os.cpu_count() or 1
+        want, cpu_dt = O.run_short_mt_timed(O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer), buf, st, nd, cores)
+        t.reset_tables()
+        t.submit(t.device_uniform_batch(d_words, m, L), 0)
+        t.wait(0)
+        got = t.collect()
+        out["cpu_baseline"] = {
+            "value": round(m * L / cpu_dt / 1e9, 6),
+            "unit": "Gbases/s",
+            "cores": cores,
+            "kind": "port",
+            "sample": "first %d reads of the same synthetic workload (%.1f Mbases), oracle/trew_oracle.c with %d threads, %.1f s" % (
+                m, m * L / 1e6, cores, cpu_dt),
+        }
+        out["parity"] = bool(got == want)
+        out["parity_note"] = "GPU tables vs CPU oracle on the %d-read sample: %s" % (m, "bit-exact" if got == want else "MISMATCH")
+
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    t.free(d_words)
+    t.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0 and out.get("parity") is False:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "trew_common.hpp"
@@ -297,25 +298,23 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     u32 ovf = 0;
     HIPCHK(ctx, hipMemcpy(&ovf, ctx->table.overflow, 4, hipMemcpyDeviceToHost));
     if (ovf) return fail(ctx, "device count table overflow: raise table_log2_slots");
-    std::vector<u64> keys(ctx->table_slots), counts(ctx->table_slots);
-    HIPCHK(ctx, hipMemcpy(keys.data(), ctx->table.keys, ctx->table_slots * 8, hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(counts.data(), ctx->table.counts, ctx->table_slots * 8, hipMemcpyDeviceToHost));
-    u64 n = 0;
-    const u32 lps = ctx->table.log2_part_slots;
-    for (u64 i = 0; i < ctx->table_slots; i++) {
-        const u64 key = keys[i];
-        if (!key) continue;
-        const int t = (int) ((key >> 60) & 7ull);
-        if (table >= 0 && t != table) continue;
-        if (n < cap && rows) {
-            rows[n].k = (int32_t) ((key >> 55) & 31ull) + 1;
-            rows[n].table = t;
-            rows[n].word_lo = ((key & ((1ull << 55) - 1ull)) << kTablePartBits) | (i >> lps);
-            rows[n].word_hi = 0;
-            rows[n].count = counts[i];
-        }
-        n++;
-    }
+    // compact on the device, copy only the occupied rows
+    const u64 dcap = rows ? cap : 0;
+    unsigned long long *d_n = nullptr;
+    trew_hip_row *d_rows = nullptr;
+    HIPCHK(ctx, hipMalloc((void **) &d_n, 8));
+    hipError_t e = hipSuccess;
+    if (dcap) e = hipMalloc((void **) &d_rows, dcap * sizeof(trew_hip_row));
+    hipStream_t st = ctx->slots[0].stream;
+    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, 8, st);
+    if (e == hipSuccess) e = launch_compact(st, ctx->table, ctx->table_slots, table, d_rows, dcap, d_n);
+    unsigned long long n = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && dcap && n) e = hipMemcpy(rows, d_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost);
+    (void) hipFree(d_n);
+    if (d_rows) (void) hipFree(d_rows);
+    HIPCHK(ctx, e);
     *n_rows = n;
     return 0;
 }
@@ -446,13 +445,33 @@ extern "C" uint64_t trew_pack_reads(const char *buf, const int64_t *st, const in
 }
 
 // ---------------------------------------------------------------- synthetic workloads
-extern "C" int trew_synth_short_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, char *out) {
-    for (uint64_t r = 0; r < n_reads; r++) {
-        const trew_synth::ReadClass c = trew_synth::read_class(seed, first_read + r);
-        char *o = out + r * (uint64_t) (read_len + 1);
-        for (uint32_t p = 0; p < read_len; p++) o[p] = trew_synth::base_char(trew_synth::short_base(seed, first_read + r, c, p, read_len));
-        o[read_len] = '\n';
+template <typename F>
+static void parallel_reads(uint64_t n, F fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (n < 4096 || nt == 1) {
+        fn(0, n);
+        return;
     }
+    std::vector<std::thread> th;
+    const uint64_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; t++) {
+        const uint64_t lo = std::min<uint64_t>(n, per * t), hi = std::min<uint64_t>(n, lo + per);
+        if (lo < hi) th.emplace_back([=] { fn(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
+extern "C" int trew_synth_short_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len, char *out) {
+    parallel_reads(n_reads, [=](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            const trew_synth::ReadClass c = trew_synth::read_class(seed, first_read + r);
+            char *o = out + r * (uint64_t) (read_len + 1);
+            for (uint32_t p = 0; p < read_len; p++)
+                o[p] = trew_synth::base_char(trew_synth::short_base(seed, first_read + r, c, p, read_len));
+            o[read_len] = '\n';
+        }
+    });
     return 0;
 }
 

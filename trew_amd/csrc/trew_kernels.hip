@@ -317,9 +317,11 @@ constexpr int kSegWords = (kMaxSegBases + 1) / 32;  // 32
 struct __attribute__((aligned(16))) ExactSmem {
     u64 seq[kSegWords + 2];    // 2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
     u32 nmask[kSegWords + 2];  // bit i = base i is not A/C/G/T or lies past the segment end
-    u64 canon[kMaxSegBases + 1];
-    u64 vmask[(kMaxSegBases + 64) / 64];
-    unsigned short cnt[kMaxSegBases + 1];  // class size at the class's first window, else 0
+    u64 canon[kMaxSegBases + 1];           // per run (fast path) or per window (fallback)
+    u64 vmask[(kMaxSegBases + 64) / 64 + 1];  // bit i: window i has no N
+    u64 emask[(kMaxSegBases + 64) / 64 + 1];  // bit i: base i == base i+k  (Lemma A: windows i, i+1 share a class)
+    unsigned short cnt[kMaxSegBases + 1];   // class size at the class's first item, else 0
+    unsigned short start[kMaxSegBases + 1]; // first window of each run
 };
 
 __device__ __forceinline__ u64 spread32(u32 v) {
@@ -358,8 +360,16 @@ __device__ __forceinline__ u64 kmask(int k) { return k >= 32 ? ~0ull : ((1ull <<
 
 // get_rot_seq, kmer.cpp:1815-1823
 __device__ __forceinline__ u64 min_rotation(u64 w, int k) {
-    u64 tmp = w, ans = w;
     const int sh = 2 * (k - 1);
+    if (k <= 16) {  // wave-uniform: the 2k-bit word fits 32 bits
+        u32 tmp = (u32) w, ans = (u32) w;
+        for (int i = 0; i < k - 1; i++) {
+            tmp = ((tmp & 3u) << sh) | (tmp >> 2);
+            ans = min(ans, tmp);
+        }
+        return ans;
+    }
+    u64 tmp = w, ans = w;
     for (int i = 0; i < k - 1; i++) {
         tmp = ((tmp & 3ull) << sh) | (tmp >> 2);
         ans = tmp < ans ? tmp : ans;
@@ -381,46 +391,57 @@ __device__ __forceinline__ bool is_homopolymer(u64 w, int k) {
 }
 
 struct KStat {
-    u32 count;  // K_MER_DATA_COUNT
-    u32 maxc;   // K_MER_DATA_MAX
-    u64 maxseq; // K_MER_DATA_MAX_SEQ
+    u32 count;   // K_MER_DATA_COUNT
+    u32 maxc;    // K_MER_DATA_MAX
+    u64 maxseq;  // K_MER_DATA_MAX_SEQ
+    u32 n_items; // entries of canon[]/cnt[] left in LDS for emit_k
 };
 
-// One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
-// 1936-1967) on the segment staged in sm.  Leaves canon[] / vmask[] / cnt[] in
-// LDS for emit_k.  All lanes must call it; the result is wave-uniform.
-__device__ KStat eval_k(ExactSmem &sm, int L, int k) {
-    KStat st;
-    st.count = 0;
-    st.maxc = 0;
-    st.maxseq = 0;
-    const int W = L - k + 1;
-    if (W <= 0) return st;
+__device__ __forceinline__ u32 base_at(const ExactSmem &sm, u32 p) {
+    return (u32) (sm.seq[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
+}
+__device__ __forceinline__ u64 window_word(const ExactSmem &sm, u32 i, int k) {
+    const u32 wi = i >> 5, sh = 2u * (i & 31u);
+    const u64 a = sm.seq[wi], b = sm.seq[wi + 1];
+    const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
+    return x >> (64 - 2 * k);
+}
+__device__ __forceinline__ bool window_valid(const ExactSmem &sm, u32 i, int k) {
+    const u32 wi = i >> 5, bi = i & 31u;
+    const u64 nmw = (((u64) sm.nmask[wi + 1] << 32) | sm.nmask[wi]) >> bi;
+    return (nmw & ((1ull << k) - 1ull)) == 0;  // no N inside the window (kmer.cpp:2190)
+}
+
+// wave argmax over per-lane (key, seq): largest class, ties to the class whose
+// last window is earliest = the first to reach the maximum in scan order
+// (strict '<' at kmer.cpp:2202).  key = (class size << 16) | (0xffff - last window)
+__device__ __forceinline__ void wave_best(u32 best, u64 best_seq, KStat &st) {
+    u32 m = best;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (u32) __shfl_xor((int) m, off));
+    const u64 who = __ballot(best == m && m != 0);
+    if (who) {
+        const int src = __ffsll((long long) who) - 1;
+        st.maxc = m >> 16;
+        st.maxseq = ((u64) (u32) __shfl((int) (best_seq >> 32), src) << 32) | (u32) __shfl((int) (u32) best_seq, src);
+    }
+}
+
+// Fallback for segments with more than 64 runs: one item per window, class sizes
+// by an all-pairs LDS-broadcast compare.  vmask[] must hold the valid-window bits.
+__device__ void eval_k_windows(ExactSmem &sm, int W, int k, KStat &st) {
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
-    __syncthreads();  // previous users of canon/cnt are done
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
-        bool valid = false;
-        u64 c = 0;
         if (i < W) {
-            const u32 wi = (u32) i >> 5, bi = (u32) i & 31u;
-            const u64 nmw = (((u64) sm.nmask[wi + 1] << 32) | sm.nmask[wi]) >> bi;
-            valid = (nmw & ((1ull << k) - 1ull)) == 0;  // no N inside the window (kmer.cpp:2190)
-            if (valid) {
-                const u64 a = sm.seq[wi], b = sm.seq[wi + 1];
-                const u32 sh = 2u * bi;
-                const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
-                c = min_rotation(x >> (64 - 2 * k), k);
-            }
-            sm.canon[i] = c;
+            const bool valid = (sm.vmask[r] >> lane) & 1ull;
+            sm.canon[i] = valid ? min_rotation(window_word(sm, (u32) i, k), k) : 0ull;
             sm.cnt[i] = 0;
         }
-        const u64 bal = __ballot(valid);
-        if (lane == 0) sm.vmask[r] = bal;
     }
     __syncthreads();
-    u32 best = 0;  // (class size << 16) | (0xffff - last window of the class)
+    u32 best = 0;
     u64 best_seq = 0;
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
@@ -430,7 +451,6 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k) {
         bool first = true;
         for (int jr = 0; jr < rounds; jr++) {
             u64 vm = rfl64(sm.vmask[jr]);
-            st.count += r == 0 ? (u32) __popcll(vm) : 0u;
             while (vm) {
                 const int jb = __ffsll((long long) vm) - 1;
                 vm &= vm - 1;
@@ -450,18 +470,108 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k) {
             }
         }
     }
-    // wave argmax: largest class, ties to the class whose last window is earliest
-    // (the first to reach the maximum in scan order, strict '<' at kmer.cpp:2202)
-    u32 m = best;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (u32) __shfl_xor((int) m, off));
-    const u64 who = __ballot(best == m && m != 0);
-    if (who) {
-        const int src = __ffsll((long long) who) - 1;
-        st.maxc = m >> 16;
-        st.maxseq = ((u64) (u32) __shfl((int) (best_seq >> 32), src) << 32) | (u32) __shfl((int) (u32) best_seq, src);
+    wave_best(best, best_seq, st);
+    st.n_items = (u32) W;
+}
+
+// One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
+// 1936-1967) on the segment staged in sm.  Lemma A: two
+// adjacent valid windows i, i+1 are in the same rotation class iff base i ==
+// base i+k, so the windows fall into maximal RUNS and only one canonical
+// rotation per run is needed; runs with equal canonical word are then merged.
+// Leaves canon[] / cnt[] in LDS for emit_k.  All lanes must call it; the
+// result is wave-uniform.
+__device__ KStat eval_k(ExactSmem &sm, int L, int k) {
+    KStat st;
+    st.count = 0;
+    st.maxc = 0;
+    st.maxseq = 0;
+    st.n_items = 0;
+    const int W = L - k + 1;
+    if (W <= 0) return st;
+    const u32 lane = lane_id();
+    const int rounds = (W + 63) >> 6;
+    __syncthreads();  // previous users of the LDS arrays are done
+    for (int r = 0; r < rounds; r++) {
+        const u32 i = (u32) r * 64u + lane;
+        bool valid = false, eq = false;
+        if ((int) i < W) {
+            valid = window_valid(sm, i, k);
+            eq = base_at(sm, i) == base_at(sm, i + (u32) k);
+        }
+        const u64 bv = __ballot(valid), be = __ballot(eq);
+        if (lane == 0) {
+            sm.vmask[r] = bv;
+            sm.emask[r] = be;
+        }
     }
-    st.count = rfl(st.count);
+    if (lane == 0) {
+        sm.vmask[rounds] = 0;
+        sm.emask[rounds] = 0;
+    }
+    __syncthreads();
+    // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
+    u32 R = 0, count = 0;
+    u64 carry = 0;
+    for (int r = 0; r < rounds; r++) {
+        const u64 vm = rfl64(sm.vmask[r]), em = rfl64(sm.emask[r]);
+        const u64 ve = vm & em;
+        const u64 startmask = vm & ~((ve << 1) | carry);
+        carry = ve >> 63;
+        count += (u32) __popcll(vm);
+        if ((startmask >> lane) & 1ull) sm.start[R + (u32) __popcll(startmask & ((1ull << lane) - 1ull))] = (unsigned short) (r * 64 + (int) lane);
+        R += (u32) __popcll(startmask);
+    }
+    st.count = count;
+    __syncthreads();
+    if (R > 64) {
+        eval_k_windows(sm, W, k, st);
+        __syncthreads();
+        return st;
+    }
+    // one lane per run
+    u64 canon = ~0ull;
+    u32 len = 0, s = 0;
+    if (lane < R) {
+        s = sm.start[lane];
+        // run length = 1 + number of consecutive j >= s with valid_j && eq_j && valid_{j+1}
+        u32 j = s;
+        len = 1;
+        for (;;) {
+            const u32 wi = j >> 6, bi = j & 63u;
+            const u64 v0 = sm.vmask[wi], v1 = sm.vmask[wi + 1];
+            const u64 cw = (v0 & sm.emask[wi] & ((v0 >> 1) | (v1 << 63))) >> bi;
+            const u64 inv = ~cw;
+            const u32 ones = inv ? (u32) (__ffsll((long long) inv) - 1) : 64u;
+            len += ones;
+            if (ones + bi < 64u) break;
+            j += ones;
+            if (j >= (u32) W) break;
+        }
+        canon = min_rotation(window_word(sm, s, k), k);
+    }
+    const u32 end = s + len - 1;
+    u32 tot = 0, last = 0;
+    bool first = true;
+    const u32 clo = (u32) canon, chi = (u32) (canon >> 32);
+    for (u32 rp = 0; rp < R; rp++) {  // wave-uniform: broadcast run rp to every lane, no LDS round trip
+        const u32 olo = (u32) __builtin_amdgcn_readlane((int) clo, (int) rp);
+        const u32 ohi = (u32) __builtin_amdgcn_readlane((int) chi, (int) rp);
+        const u32 olen = (u32) __builtin_amdgcn_readlane((int) len, (int) rp);
+        const u32 oend = (u32) __builtin_amdgcn_readlane((int) end, (int) rp);
+        const bool eq = olo == clo && ohi == chi;
+        tot += eq ? olen : 0u;
+        last = eq ? oend : last;
+        first = first && !(eq && rp < lane);
+    }
+    u32 key = 0;
+    if (lane < R) {
+        key = (tot << 16) | (0xffffu - last);
+        sm.canon[lane] = canon;
+        sm.cnt[lane] = first ? (unsigned short) tot : (unsigned short) 0;
+    }
+    wave_best(key, canon, st);
+    st.n_items = R;
     __syncthreads();
     return st;
 }
@@ -469,10 +579,9 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k) {
 // add every class of the k just evaluated to the tables in table_mask (bit t).
 // strand_canon: key = MIN(w, rot(rc(w))) (k_mer_target, kmer.cpp:1979-1988) else the
 // rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
-__device__ void emit_k(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
-    const int W = L - k + 1;
+__device__ void emit_k(ExactSmem &sm, const DevTable &T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
     const u32 lane = lane_id();
-    for (int i = (int) lane; i < W; i += 64) {
+    for (u32 i = lane; i < n_items; i += 64) {
         const u32 c = sm.cnt[i];
         if (c) {
             u64 w = sm.canon[i];
@@ -532,8 +641,8 @@ __device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, i
 // record the histogram of segment (already staged) at k into tables
 __device__ void record(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
     if (k <= 0 || table_mask == 0) return;
-    eval_k(sm, L, k);
-    emit_k(sm, T, L, k, table_mask, strand_canon);
+    const KStat st = eval_k(sm, L, k);
+    emit_k(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
 // k_mer_target, kmer.cpp:1894-2017, on the staged whole read
@@ -544,7 +653,7 @@ __device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int
     u32 tm = 0;
     if (want_high && f >= P.high) tm |= 1u << TREW_TABLE_BOTH_HIGH;
     if (want_low && f >= P.low) tm |= 1u << TREW_TABLE_BOTH_LOW;
-    if (tm) emit_k(sm, T, L, k, tm, true);
+    if (tm) emit_k(sm, T, st.n_items, k, tm, true);
 }
 
 // buffer_task, kmer.cpp:111-173
@@ -657,6 +766,26 @@ __global__ void table_add_rows_kernel(DevTable T, const trew_hip_row *rows, u64 
     if (i < n) table_add(T, rows[i].table, rows[i].k, rows[i].word_lo, rows[i].count);
 }
 
+// compaction of the sparse table into rows (collect): one atomic per occupied slot
+__global__ void table_compact_kernel(DevTable T, u64 n_slots, int table, trew_hip_row *rows, u64 cap, unsigned long long *n_rows) {
+    const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const u64 key = T.keys[i];
+    if (!key) return;
+    const int t = (int) ((key >> 60) & 7ull);
+    if (table >= 0 && t != table) return;
+    const u64 at = atomicAdd(n_rows, 1ull);
+    if (at < cap) {
+        trew_hip_row r;
+        r.k = (int32_t) ((key >> 55) & 31ull) + 1;
+        r.table = t;
+        r.word_lo = ((key & ((1ull << 55) - 1ull)) << kTablePartBits) | (i >> T.log2_part_slots);
+        r.word_hi = 0;
+        r.count = T.counts[i];
+        rows[at] = r;
+    }
+}
+
 // ------------------------------------------------------------------ synthetic generators
 __global__ void synth_short_kernel(u64 seed, u64 first_read, u64 n_reads, u32 read_len, u32 *words) {
     const u32 nw = (read_len + 31u) >> 5;
@@ -743,6 +872,12 @@ hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevB
 hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(table_add_rows_kernel, dim3((u32) ((n + 255) / 256)), dim3(256), 0, st, T, d_rows, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, int table, trew_hip_row *d_rows, u64 cap,
+                          unsigned long long *d_n) {
+    hipLaunchKernelGGL(table_compact_kernel, dim3((u32) ((n_slots + 255) / 256)), dim3(256), 0, st, T, n_slots, table, d_rows, cap, d_n);
     return hipGetLastError();
 }
 

@@ -13,6 +13,8 @@ hipError_t launch_filter(hipStream_t st, int nw, const DevParams &P, const DevBa
 hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
                         const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R);
 hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n);
+hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, int table, trew_hip_row *d_rows, u64 cap,
+                          unsigned long long *d_n);
 hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
 hipError_t launch_synth_pair(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
 
