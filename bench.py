@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--max-mer", type=int, default=32)
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="TREW_FLAG_* (debug experiments only)")
     args = ap.parse_args()
 
     import torch
@@ -45,7 +46,7 @@ def main():
 
     import trew_amd as T
     from trew_amd import capi
-    from trew_amd.dist import allreduce_tables
+    from trew_amd.dist import allreduce_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -64,7 +65,7 @@ def main():
     n, L = args.reads, args.read_len
     stride = 3 * ((L + 31) // 32)
     t = T.TrewHip(mode=T.MODE_SHORT, min_mer=args.min_mer, max_mer=args.max_mer, device=dev.index, n_slots=1,
-                  max_batch_words=16, max_batch_reads=n, table_log2_slots=20)
+                  max_batch_words=16, max_batch_reads=n, table_log2_slots=20, flags=args.flags)
     d_words = t.malloc(n * stride * 4 + 64)
     first_read = rank * n  # contiguous read-index ranges per rank
     t.synth_short_device(SEED, first_read, n, L, d_words)
@@ -85,13 +86,16 @@ def main():
     filt_ms, exact_ms = [], []
     barrier()
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         step()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
         a, b, nflag = t.last_timing(0)  # HIP events on the kernels' own stream
         filt_ms.append(a)
         exact_ms.append(b)
-    tables = t.collect()
-    merged = allreduce_tables(tables, device=dev)
+    rows = t.collect_rows()
+    merged = allreduce_rows(rows, device=dev)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -145,7 +149,8 @@ def main():
                         % (evals / ((f_avg + e_avg) * 1e-3), evals / ((f_avg + e_avg) * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
             },
             "flagged_reads_per_step": int(nflag),
-            "table_rows": sum(len(v) for v in merged.values()),
+            "host_ms_per_step": round(sum(host_ms) / len(host_ms), 4),
+            "table_rows": int(len(merged)),
         }
 
     # CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1 only)

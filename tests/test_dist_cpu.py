@@ -1,0 +1,66 @@
+"""world_size-2 gloo test of the cross-rank table reduction (the only exchange step)."""
+import os
+import random
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from trew_amd import capi
+from trew_amd.dist import allreduce_rows, allreduce_tables, shard_range
+
+
+def _make(rank):
+    rnd = random.Random(100 + rank)
+    t = {name: {} for name in capi.TABLE_NAMES}
+    for name in capi.TABLE_NAMES:
+        for _ in range(40):
+            k = rnd.randint(5, 32)
+            w = rnd.getrandbits(2 * k) if rnd.random() < 0.7 else (0x3FF if k >= 5 else 1)  # some keys shared by both ranks
+            t[name][(k, w)] = t[name].get((k, w), 0) + rnd.randint(1, 10 ** 9)
+    t["both_high"][(32, 2 ** 64 - 1)] = 7 + rank  # top bit set: exercises the u64 <-> i64 mapping
+    return t
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = _make(rank)
+    merged = allreduce_tables(mine)
+    rows = allreduce_rows(capi.tables_to_rows(mine))
+    q.put((rank, merged, capi.rows_to_tables(rows)))
+    dist.destroy_process_group()
+
+
+def test_allreduce_tables_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = {name: {} for name in capi.TABLE_NAMES}
+    for r in range(world):
+        for name, d in _make(r).items():
+            for key, c in d.items():
+                want[name][key] = want[name].get(key, 0) + c
+    for rank, merged, merged_rows in res:
+        assert merged == want
+        assert merged_rows == want
+
+
+def test_single_process_passthrough_and_shards():
+    t = _make(0)
+    assert allreduce_tables(t) == t
+    rows = capi.tables_to_rows(t)
+    assert capi.rows_to_tables(allreduce_rows(rows)) == t
+    n, w = 1_000_000_007, 8
+    cover = [shard_range(n, r, w) for r in range(w)]
+    assert cover[0][0] == 0 and cover[-1][1] == n
+    assert all(cover[i][1] == cover[i + 1][0] for i in range(w - 1))

@@ -52,7 +52,27 @@ class Row(C.Structure):
                 ("count", C.c_uint64)]
 
 
+ROW_DTYPE = np.dtype([("k", "<i4"), ("table", "<i4"), ("word_lo", "<u8"), ("word_hi", "<u8"), ("count", "<u8")])
+assert ROW_DTYPE.itemsize == C.sizeof(Row)
+
 _lib = None
+
+
+def rows_to_tables(rows):
+    """Structured row array -> {name: {(k, word): count}}."""
+    out = {name: {} for name in TABLE_NAMES}
+    if len(rows) == 0:
+        return out
+    for t, k, lo, hi, c in zip(rows["table"].tolist(), rows["k"].tolist(), rows["word_lo"].tolist(),
+                               rows["word_hi"].tolist(), rows["count"].tolist()):
+        out[TABLE_NAMES[t]][(k, (hi << 64) | lo)] = c
+    return out
+
+
+def tables_to_rows(tables):
+    items = [(k, t, w & 0xFFFFFFFFFFFFFFFF, w >> 64, c)
+             for t, name in enumerate(TABLE_NAMES) for (k, w), c in tables.get(name, {}).items()]
+    return np.array(items, dtype=ROW_DTYPE) if items else np.zeros(0, dtype=ROW_DTYPE)
 
 
 def load():
@@ -199,30 +219,27 @@ class TrewHip:
 
     # ---- results ----
     def collect_rows(self, table=-1):
+        """Rows of one table (or all, table=-1) as a structured numpy array (ROW_DTYPE)."""
         n = C.c_uint64(0)
         self._chk(self.lib.trew_hip_collect(self.ctx, table, None, 0, C.byref(n)), "trew_hip_collect")
-        rows = (Row * max(1, n.value))()
-        self._chk(self.lib.trew_hip_collect(self.ctx, table, rows, n.value, C.byref(n)), "trew_hip_collect")
-        return rows, n.value
+        rows = np.zeros(max(1, n.value), dtype=ROW_DTYPE)
+        self._chk(self.lib.trew_hip_collect(self.ctx, table, C.cast(rows.ctypes.data, C.POINTER(Row)), n.value,
+                                            C.byref(n)), "trew_hip_collect")
+        return rows[: n.value]
 
     def collect(self):
         """The six tables as {name: {(k, word): count}}."""
-        rows, n = self.collect_rows(-1)
-        out = {name: {} for name in TABLE_NAMES}
-        for i in range(n):
-            r = rows[i]
-            out[TABLE_NAMES[r.table]][(r.k, (r.word_hi << 64) | r.word_lo)] = int(r.count)
-        return out
+        return rows_to_tables(self.collect_rows(-1))
 
     def reset_tables(self):
         self._chk(self.lib.trew_hip_reset_tables(self.ctx), "trew_hip_reset_tables")
 
     def add_rows(self, tables):
-        items = [(t, k, w, c) for t, name in enumerate(TABLE_NAMES) for (k, w), c in tables.get(name, {}).items()]
-        rows = (Row * max(1, len(items)))()
-        for i, (t, k, w, c) in enumerate(items):
-            rows[i] = Row(k, t, w & 0xFFFFFFFFFFFFFFFF, w >> 64, c)
-        self._chk(self.lib.trew_hip_add_rows(self.ctx, rows, len(items)), "trew_hip_add_rows")
+        rows = tables if isinstance(tables, np.ndarray) else tables_to_rows(tables)
+        rows = np.ascontiguousarray(rows, dtype=ROW_DTYPE)
+        if len(rows):
+            self._chk(self.lib.trew_hip_add_rows(self.ctx, C.cast(rows.ctypes.data, C.POINTER(Row)), len(rows)),
+                      "trew_hip_add_rows")
 
     def segment_results(self, n_reads, slot=0):
         kh = np.zeros(n_reads, dtype=np.int32)

@@ -186,7 +186,7 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
 // Longest segment any slot of any read of the batch can have, and validation of
 // the read-length limits (short mode aborts above MAX_SEQ = 1000, kmer.cpp:1006-1009;
 // the build applies the same limit to pair mode).
-static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_seg) {
+static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_seg, u32 *max_len) {
     u32 maxlen = 0;
     if (b->lengths) {
         if (b->on_device) {
@@ -213,6 +213,7 @@ static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_s
         ms = maxlen;
     }
     *max_seg = ms;
+    *max_len = maxlen;
     return 0;
 }
 
@@ -252,8 +253,8 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
     HIPCHK(ctx, hipSetDevice(ctx->p.device));
     Slot &s = ctx->slots[(size_t) slot];
-    u32 max_seg = 0;
-    if (int rc = batch_geometry(ctx, batch, &max_seg)) return rc;
+    u32 max_seg = 0, max_len = 0;
+    if (int rc = batch_geometry(ctx, batch, &max_seg, &max_len)) return rc;
     DevBatch db;
     if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
     s.n_units = db.n_units;
@@ -270,8 +271,17 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     HIPCHK(ctx, hipEventRecord(s.e0, s.stream));
     HIPCHK(ctx, launch_filter(s.stream, pick_nw(max_seg), ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
     HIPCHK(ctx, hipEventRecord(s.e1, s.stream));
-    const u32 grid = (u32) std::min<u64>((u64) ctx->n_cu * 8ull, std::max<u64>(db.n_units, 1));
-    HIPCHK(ctx, launch_exact(s.stream, grid, ctx->dp, db, ctx->table, s.d_wl, s.d_wl_count, wl_cap, s.res));
+    // LDS working set of the exact kernel: the longest segment it may stage (the whole
+    // read for k_mer_target / the whole-read check; a slice pair in long mode)
+    const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
+    const u32 cap = std::max<u32>(64u, ((exact_seg + 1 + 63u) / 64u) * 64u);
+    const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
+    const u32 lds = exact_lds_bytes_host(cap, rawwords);
+    const u32 waves_per_cu = std::max<u32>(1u, std::min<u32>(32u, (160u * 1024u) / lds));
+    const u32 grid = (u32) std::min<u64>((u64) ctx->n_cu * waves_per_cu, std::max<u64>(db.n_units, 1));
+    DevTable tbl = ctx->table;
+    if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
+    HIPCHK(ctx, launch_exact(s.stream, grid, ctx->dp, db, tbl, s.d_wl, s.d_wl_count, wl_cap, s.res, cap, rawwords));
     HIPCHK(ctx, hipEventRecord(s.e2, s.stream));
     s.timed = true;
     return 0;
@@ -365,8 +375,8 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     if (slots_per_read < 1 || slots_per_read > kMaxSlots) return fail(ctx, "slots_per_read out of range");
     if (int rc = sync_all(ctx)) return rc;
     Slot &s = ctx->slots[0];
-    u32 max_seg = 0;
-    if (int rc = batch_geometry(ctx, batch, &max_seg)) return rc;
+    u32 max_seg = 0, max_len = 0;
+    if (int rc = batch_geometry(ctx, batch, &max_seg, &max_len)) return rc;
     DevBatch db;
     if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
     if (db.n_units == 0) return 0;

@@ -287,6 +287,7 @@ __device__ __forceinline__ u64 hash64(u64 x) {
 }
 
 __device__ void table_add(const DevTable &T, int table, int k, u64 word, u64 cnt) {
+    if (T.log2_part_slots == 0xffffffffu) return;  // TREW_FLAG_DEBUG_NO_EMIT (timing experiments only)
     const u32 part = (u32) (word & ((1u << kTablePartBits) - 1u));
     const u64 key = (1ull << 63) | ((u64) table << 60) | ((u64) (k - 1) << 55) | (word >> kTablePartBits);
     const u32 S = 1u << T.log2_part_slots, mask = S - 1u;
@@ -312,17 +313,37 @@ __device__ void table_add(const DevTable &T, int table, int k, u64 word, u64 cnt
 }
 
 // ------------------------------------------------------------------ exact path
-constexpr int kSegWords = (kMaxSegBases + 1) / 32;  // 32
-
-struct __attribute__((aligned(16))) ExactSmem {
-    u64 seq[kSegWords + 2];    // 2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
-    u32 nmask[kSegWords + 2];  // bit i = base i is not A/C/G/T or lies past the segment end
-    u64 canon[kMaxSegBases + 1];           // per run (fast path) or per window (fallback)
-    u64 vmask[(kMaxSegBases + 64) / 64 + 1];  // bit i: window i has no N
-    u64 emask[(kMaxSegBases + 64) / 64 + 1];  // bit i: base i == base i+k  (Lemma A: windows i, i+1 share a class)
-    unsigned short cnt[kMaxSegBases + 1];   // class size at the class's first item, else 0
-    unsigned short start[kMaxSegBases + 1]; // first window of each run
+// LDS working set of one wave, carved from dynamic LDS and sized by the longest
+// segment of the batch (cap bases, a multiple of 64): 2.6 KB for 150-bp reads, so
+// 8 waves per SIMD stay resident and hide the global/LDS latency chains.
+struct ExactSmem {
+    u64 *seq;     // [cap/32+2] 2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
+    u64 *canon;   // [cap] per run (fast path) or per window (fallback)
+    u64 *vmask;   // [cap/64+2] bit i: window i has no N
+    u64 *emask;   // [cap/64+2] bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
+    u32 *nmask;   // [cap/32+2] bit i = base i is not A/C/G/T or lies past the segment end
+    u32 *raw;     // [2][rawwords] the unit's packed triples, staged once
+    unsigned short *cnt;    // [cap] class size at the class's first item, else 0
+    unsigned short *start;  // [cap] first window of each run
+    u32 cap, rawwords;
 };
+
+__host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords) {
+    return (cap / 32 + 2) * 8 + cap * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 16;
+}
+
+__device__ inline void carve_smem(ExactSmem &sm, unsigned char *base, u32 cap, u32 rawwords) {
+    sm.cap = cap;
+    sm.rawwords = rawwords;
+    sm.seq = (u64 *) base;
+    sm.canon = sm.seq + (cap / 32 + 2);
+    sm.vmask = sm.canon + cap;
+    sm.emask = sm.vmask + (cap / 64 + 2);
+    sm.nmask = (u32 *) (sm.emask + (cap / 64 + 2));
+    sm.raw = sm.nmask + (cap / 32 + 2);
+    sm.cnt = (unsigned short *) (sm.raw + 2 * rawwords);
+    sm.start = sm.cnt + cap;
+}
 
 __device__ __forceinline__ u64 spread32(u32 v) {
     u64 x = v;
@@ -335,10 +356,22 @@ __device__ __forceinline__ u64 spread32(u32 v) {
 }
 
 // stage bases [s, s+L) of a read into LDS (one wave)
+// copy a read's triples into LDS once; later segment staging reads LDS, not HBM
+__device__ ReadRef stage_read(ExactSmem &sm, const ReadRef &rd, int mate) {
+    u32 *dst = sm.raw + (u32) mate * sm.rawwords;
+    const u32 n = 3u * rd.nw;
+    if (n > sm.rawwords) return rd;  // does not fit (long mode): keep reading global memory
+    for (u32 j = lane_id(); j < n; j += 64) dst[j] = rd.w[j];
+    ReadRef r = rd;
+    r.w = dst;
+    return r;
+}
+
 __device__ void load_segment(ExactSmem &sm, const ReadRef &rd, u32 s, u32 L) {
-    const u32 lane = lane_id();
+    __syncthreads();
     const u32 nwords = (L + 31u) >> 5;
-    if (lane < kSegWords + 2) {
+    const u32 segwords = sm.cap / 32 + 2;
+    for (u32 lane = lane_id(); lane < segwords; lane += 64) {
         u64 sq = 0;
         u32 nmv = 0xffffffffu;
         if (lane < nwords) {
@@ -658,7 +691,7 @@ __device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int
 
 // buffer_task, kmer.cpp:111-173
 __device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
-    const ReadRef rd = get_read(B, it.unit);
+    const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
     const int n = (int) rd.len;
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
@@ -726,7 +759,7 @@ __device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, 
 // TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
 __device__ void run_segment(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it,
                             const SegResults &R) {
-    const ReadRef rd = get_read(B, it.unit);
+    const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
     load_segment(sm, rd, 0, s.len);
@@ -746,8 +779,10 @@ __device__ void run_segment(ExactSmem &sm, const DevParams &P, const DevBatch &B
 }
 
 __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
-                                                   const u32 *wl_count, u32 wl_cap, SegResults R) {
-    __shared__ ExactSmem sm;
+                                                   const u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ExactSmem sm;
+    carve_smem(sm, lds_raw, cap, rawwords);
     u32 n = *wl_count;
     n = n < wl_cap ? n : wl_cap;
     for (u32 w = blockIdx.x; w < n; w += gridDim.x) {
@@ -863,9 +898,12 @@ hipError_t launch_filter(hipStream_t st, int nw, const DevParams &P, const DevBa
     return hipGetLastError();
 }
 
+u32 exact_lds_bytes_host(u32 cap, u32 rawwords) { return exact_lds_bytes(cap, rawwords); }
+
 hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
-                        const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R) {
-    hipLaunchKernelGGL(exact_kernel, dim3(grid), dim3(64), 0, st, P, B, T, wl, wl_count, wl_cap, R);
+                        const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords) {
+    hipLaunchKernelGGL(exact_kernel, dim3(grid), dim3(64), exact_lds_bytes(cap, rawwords), st, P, B, T, wl, wl_count, wl_cap, R, cap,
+                       rawwords);
     return hipGetLastError();
 }
 

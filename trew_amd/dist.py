@@ -82,6 +82,50 @@ def allreduce_tables(tables, device="cpu", group=None):
     return keys_to_tables(dictionary, dense.cpu().tolist()[: len(dictionary)])
 
 
+def allreduce_rows(rows, device="cpu", group=None):
+    """Array form of allreduce_tables: structured rows (capi.ROW_DTYPE) in, merged rows out.
+    Same exchange (all_gather of keys -> common dictionary -> one all_reduce of the dense
+    count vector), no per-row Python work."""
+    import numpy as np
+
+    from .capi import ROW_DTYPE
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return rows
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    keys = np.stack([rows["table"].astype(np.int64) * 128 + rows["k"].astype(np.int64),
+                     rows["word_lo"].view(np.int64), rows["word_hi"].view(np.int64)], axis=1) if len(rows) else np.zeros((0, 3), np.int64)
+    n_local = torch.tensor([len(keys)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(x.item()) for x in sizes]
+    n_max = max(max(sizes), 1)
+    local = torch.zeros((n_max, 3), dtype=torch.int64, device=device)
+    if len(keys):
+        local[: len(keys)] = torch.from_numpy(keys).to(device)
+    gathered = [torch.zeros((n_max, 3), dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(gathered, local, group=group)
+    parts = [gathered[r][: sizes[r]].cpu().numpy() for r in range(world)]
+    cat = np.concatenate(parts, axis=0) if sum(sizes) else np.zeros((0, 3), np.int64)
+    if len(cat) == 0:
+        return rows
+    dictionary, inv = np.unique(cat, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    off = sum(sizes[:rank])
+    dense = torch.zeros(len(dictionary), dtype=torch.int64, device=device)
+    if len(keys):
+        dense[torch.from_numpy(inv[off: off + len(keys)]).to(device)] = torch.from_numpy(rows["count"].astype(np.int64)).to(device)
+    dist.all_reduce(dense, op=dist.ReduceOp.SUM, group=group)
+    out = np.zeros(len(dictionary), dtype=ROW_DTYPE)
+    out["table"] = dictionary[:, 0] // 128
+    out["k"] = dictionary[:, 0] % 128
+    out["word_lo"] = dictionary[:, 1].view(np.uint64)
+    out["word_hi"] = dictionary[:, 2].view(np.uint64)
+    out["count"] = dense.cpu().numpy().view(np.uint64)
+    return out
+
+
 def shard_range(n_total, rank, world):
     """Contiguous split of n_total reads over ranks: [lo, hi)."""
     per = (n_total + world - 1) // world
