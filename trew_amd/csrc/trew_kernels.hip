@@ -428,6 +428,7 @@ struct KStat {
     u32 maxc;    // K_MER_DATA_MAX
     u64 maxseq;  // K_MER_DATA_MAX_SEQ
     u32 n_items; // entries of canon[]/cnt[] left in LDS for emit_k
+    bool pruned; // the bucket bound proved MAX/COUNT < need: maxc/maxseq were not computed
 };
 
 __device__ __forceinline__ u32 base_at(const ExactSmem &sm, u32 p) {
@@ -514,28 +515,55 @@ __device__ void eval_k_windows(ExactSmem &sm, int W, int k, KStat &st) {
 // rotation per run is needed; runs with equal canonical word are then merged.
 // Leaves canon[] / cnt[] in LDS for emit_k.  All lanes must call it; the
 // result is wave-uniform.
-__device__ KStat eval_k(ExactSmem &sm, int L, int k) {
+//
+// need > 0 asks for an early exit: windows of one class share their base
+// composition, so the largest of the 8 (#lo, #hi, #A mod 2) parity buckets
+// bounds MAX from above; if even that bound gives a frequency below `need`
+// (the smallest threshold this k still has to reach in decide()), the k cannot
+// be accepted and the per-run canonicalisation is skipped (st.pruned).
+__device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
     KStat st;
     st.count = 0;
     st.maxc = 0;
     st.maxseq = 0;
     st.n_items = 0;
+    st.pruned = false;
     const int W = L - k + 1;
     if (W <= 0) return st;
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
+    const u64 m5 = 0x5555555555555555ull & kmask(k);
+    u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
     __syncthreads();  // previous users of the LDS arrays are done
     for (int r = 0; r < rounds; r++) {
         const u32 i = (u32) r * 64u + lane;
-        bool valid = false, eq = false;
+        bool valid = false, eq = false, p1 = false, p2 = false, p3 = false;
         if ((int) i < W) {
             valid = window_valid(sm, i, k);
-            eq = base_at(sm, i) == base_at(sm, i + (u32) k);
+            const u64 w = window_word(sm, i, k);
+            eq = (u32) (w >> (2 * k - 2)) == base_at(sm, i + (u32) k);
+            p1 = __popcll(w & m5) & 1;
+            p2 = __popcll((w >> 1) & m5) & 1;
+            p3 = __popcll(w & (w >> 1) & m5) & 1;
         }
         const u64 bv = __ballot(valid), be = __ballot(eq);
         if (lane == 0) {
             sm.vmask[r] = bv;
             sm.emask[r] = be;
+        }
+        if (need > 0.0) {
+            const u64 f1 = __ballot(p1), f2 = __ballot(p2), f3 = __ballot(p3);
+            const u64 a1 = bv & f1, a0 = bv ^ a1;
+            const u64 a11 = a1 & f2, a10 = a1 ^ a11, a01 = a0 & f2, a00 = a0 ^ a01;
+            const u64 c111 = a11 & f3, c101 = a10 & f3, c011 = a01 & f3, c001 = a00 & f3;
+            b7 += (u32) __popcll(c111);
+            b6 += (u32) __popcll(a11 ^ c111);
+            b5 += (u32) __popcll(c101);
+            b4 += (u32) __popcll(a10 ^ c101);
+            b3 += (u32) __popcll(c011);
+            b2 += (u32) __popcll(a01 ^ c011);
+            b1 += (u32) __popcll(c001);
+            b0 += (u32) __popcll(a00 ^ c001);
         }
     }
     if (lane == 0) {
@@ -543,6 +571,18 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k) {
         sm.emask[rounds] = 0;
     }
     __syncthreads();
+    if (need > 0.0) {
+        u32 cnt = 0;
+        for (int r = 0; r < rounds; r++) cnt += (u32) __popcll(rfl64(sm.vmask[r]));
+        const u32 mb = max(max(max(b0, b1), max(b2, b3)), max(max(b4, b5), max(b6, b7)));
+        // MAX <= mb and IEEE division is monotone in the numerator, so MAX/COUNT <= mb/COUNT < need
+        if (cnt == 0 || (double) rfl(mb) / (double) cnt < need) {
+            st.count = cnt;
+            st.pruned = true;
+            __syncthreads();
+            return st;
+        }
+    }
     // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
     u32 R = 0, count = 0;
     u64 carry = 0;
@@ -651,17 +691,24 @@ __device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, i
     u64 acc_low = 0, acc_high = 0;
     for (int k = kmin; k <= kmax; k++) {
         if (!((cand >> (k - 1)) & 1ull)) continue;
-        const KStat st = eval_k(sm, L, k);
-        if (st.count == 0) continue;  // 0/0 = NaN fails every >=
+        // a multiple of an accepted k is never accepted and never moves the running
+        // frequency (kmer.cpp:2225-2236), so a k closed in both loops needs no evaluation
+        const bool lo_open = !divides_any(k, acc_low), hi_open = !divides_any(k, acc_high);
+        if (!lo_open && !hi_open) continue;
+        const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
+        const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
+        const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
+        const KStat st = eval_k(sm, L, k, need);
+        if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
         if (is_homopolymer(st.maxseq, k)) continue;
-        if (f >= (P.low > tf_low ? P.low : tf_low) && !divides_any(k, acc_low)) {
+        if (lo_open && f >= thr_lo) {
             d.kl = k;
             tf_low = f;
             acc_low |= 1ull << (k - 1);
             d.sl = st.maxseq;
         }
-        if (f >= (P.high > tf_high ? P.high : tf_high) && !divides_any(k, acc_high)) {
+        if (hi_open && f >= thr_hi) {
             d.kh = k;
             tf_high = f;
             acc_high |= 1ull << (k - 1);
@@ -674,13 +721,13 @@ __device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, i
 // record the histogram of segment (already staged) at k into tables
 __device__ void record(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
     if (k <= 0 || table_mask == 0) return;
-    const KStat st = eval_k(sm, L, k);
+    const KStat st = eval_k(sm, L, k, 0.0);
     emit_k(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
 // k_mer_target, kmer.cpp:1894-2017, on the staged whole read
 __device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
-    const KStat st = eval_k(sm, L, k);
+    const KStat st = eval_k(sm, L, k, 0.0);
     if (st.count == 0) return;
     const double f = is_homopolymer(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
     u32 tm = 0;
