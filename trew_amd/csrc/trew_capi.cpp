@@ -187,31 +187,48 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
 // the read-length limits (short mode aborts above MAX_SEQ = 1000, kmer.cpp:1006-1009;
 // the build applies the same limit to pair mode).
 static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_seg, u32 *max_len) {
-    u32 maxlen = 0;
-    if (b->lengths) {
-        if (b->on_device) {
-            maxlen = (u32) b->max_length;  // caller-provided maximum read length
-            if (maxlen == 0) maxlen = kMaxSegBases;
-        } else {
-            for (u64 i = 0; i < b->n_reads; i++) maxlen = std::max(maxlen, b->lengths[i]);
+    const int mode = ctx->p.mode;
+    const int MINM = ctx->p.min_mer, MAXM = ctx->p.max_mer, SL = ctx->dp.slice_len;
+    u32 maxlen = 0, ms = 0;
+    // longest segment of one unit, from the same geometry function the kernels use
+    auto unit_seg = [&](u32 n1, u32 n2) {
+        u32 m = 0;
+        for (int slot = 0; slot < mode_slots(mode); slot++) {
+            const Segment sg = get_segment(mode, slot, n1, n2, MINM, MAXM, SL);
+            if (sg.valid) m = std::max(m, sg.len);
         }
+        return m;
+    };
+    if (b->lengths && !b->on_device) {
+        if (mode == TREW_MODE_PAIR) {
+            for (u64 i = 0; i + 1 < b->n_reads; i += 2) {
+                maxlen = std::max(maxlen, std::max(b->lengths[i], b->lengths[i + 1]));
+                ms = std::max(ms, unit_seg(b->lengths[i], b->lengths[i + 1]));
+            }
+        } else {
+            for (u64 i = 0; i < b->n_reads; i++) {
+                maxlen = std::max(maxlen, b->lengths[i]);
+                ms = std::max(ms, unit_seg(b->lengths[i], 0));
+            }
+        }
+    } else if (b->lengths) {
+        // device-resident ragged batch: only the caller's max_length hint is known
+        maxlen = b->max_length > 0 ? (u32) b->max_length : (u32) kMaxSegBases;
+        if (mode == TREW_MODE_SHORT || mode == TREW_MODE_PAIR)
+            ms = std::max((maxlen + 1) / 2, std::min<u32>(maxlen, (u32) (4 * MAXM - 1)));
+        else if (mode == TREW_MODE_LONG)
+            ms = std::min<u32>(maxlen, (u32) (2 * SL - 1));
+        else
+            ms = maxlen;
     } else {
         maxlen = b->uniform_length;
+        ms = unit_seg(maxlen, maxlen);
     }
-    const int mode = ctx->p.mode;
+    // short mode aborts above MAX_SEQ = 1000 (kmer.cpp:1006-1009); the build applies the
+    // same limit to pair mode, which the reference leaves unchecked
     if ((mode == TREW_MODE_SHORT || mode == TREW_MODE_PAIR) && maxlen > 1000)
         return fail(ctx, "This mode is designed for short-read sequencing. Please use 'trew long'.");
     if (mode == TREW_MODE_SEGMENT && maxlen > (u32) kMaxSegBases) return fail(ctx, "segment longer than 1023 bases");
-    u32 ms;
-    if (mode == TREW_MODE_SHORT || mode == TREW_MODE_PAIR) {
-        const u32 half = (maxlen + 1) / 2;
-        const u32 whole = std::min<u32>(maxlen, (u32) (4 * ctx->p.max_mer - 1));
-        ms = std::max(half, whole);
-    } else if (mode == TREW_MODE_LONG) {
-        ms = std::min<u32>(maxlen, (u32) (2 * ctx->dp.slice_len - 1));
-    } else {
-        ms = maxlen;
-    }
     *max_seg = ms;
     *max_len = maxlen;
     return 0;
@@ -269,7 +286,7 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
     HIPCHK(ctx, hipEventRecord(s.e0, s.stream));
-    HIPCHK(ctx, launch_filter(s.stream, pick_nw(max_seg), ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
+    HIPCHK(ctx, launch_filter(s.stream, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
     HIPCHK(ctx, hipEventRecord(s.e1, s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
@@ -386,7 +403,7 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
     if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 4, s.stream);
     if (e == hipSuccess)
-        e = launch_filter(s.stream, pick_nw(max_seg), ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
+        e = launch_filter(s.stream, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
     if (e == hipSuccess) e = hipMemcpy(cand, d, bytes, hipMemcpyDeviceToHost);
     (void) hipFree(d);

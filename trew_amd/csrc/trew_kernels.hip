@@ -25,6 +25,8 @@
 // No CUDA shims, no dual paths: HIP for gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "trew_common.hpp"
 #include "trew_launch.hpp"
 #include "trew_synth.hpp"
@@ -113,13 +115,91 @@ __device__ __forceinline__ void prefix_parity(const u32 (&f)[NW], u32 (&P)[NW]) 
     }
 }
 
+// word j of (x >> k), k = 32*WS + bs, zero-extended above word NW-1
+template <int NW, int WS>
+__device__ __forceinline__ u32 shr_word(const u32 (&x)[NW], int j, u32 bs) {
+    const u32 lo = (j + WS < NW) ? x[j + WS < NW ? j + WS : 0] : 0u;
+    const u32 hi = (j + WS + 1 < NW) ? x[j + WS + 1 < NW ? j + WS + 1 : 0] : 0u;
+    return alignbit(hi, lo, bs);
+}
+
+// One k of the prefilter.  V holds V_k (windows with no N) on entry and V_{k+1} on exit.
+// Stage 1 uses two parities (4 buckets); the third parity (8 buckets) is evaluated only
+// when some lane of the wave would otherwise get its FIRST candidate from the 4-bucket
+// bound.  Lanes that already own a candidate keep the looser -- still sound -- verdict:
+// the exact kernel prunes their extra candidates itself (eval_k's `need`).  The result of
+// a lane never depends on its neighbours: 8-bucket max <= 4-bucket max.
+template <int NW, int WS>
+__device__ __forceinline__ void filter_k(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW],
+                                         const u32 (&v1)[NW], u32 (&V)[NW], int k, int nww, int kmin, int kmax,
+                                         float lowf, u64 &cand) {
+    const u32 bs = (u32) k & 31u;
+    u32 c00 = 0, c01 = 0, c10 = 0, c11 = 0, count = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        if (j < nww) {  // wave-uniform: words that can still hold a window
+            const u32 F1 = P1[j] ^ shr_word<NW, WS>(P1, j, bs), F2 = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
+            const u32 v = V[j];
+            const u32 a1 = v & F1, a0 = v ^ a1;
+            const u32 a11 = a1 & F2, a01 = a0 & F2;
+            count += __popc(v);
+            c11 += __popc(a11);
+            c10 += __popc(a1 ^ a11);
+            c01 += __popc(a01);
+            c00 += __popc(a0 ^ a01);
+        }
+    }
+    const u32 m4 = max(max(c00, c01), max(c10, c11));
+    const bool inrange = count != 0u && k >= kmin && k <= kmax;
+    const float thr = (float) count * lowf;  // lowf < LOW*(1-1e-6): float rounding can only keep more
+    const bool pass4 = inrange && (float) m4 >= thr;
+    bool pass = pass4;
+    if (__any(pass4 && cand == 0)) {
+        u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            if (j < nww) {
+                const u32 F1 = P1[j] ^ shr_word<NW, WS>(P1, j, bs), F2 = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
+                const u32 F3 = P3[j] ^ shr_word<NW, WS>(P3, j, bs);
+                const u32 v = V[j];
+                const u32 a1 = v & F1, a0 = v ^ a1;
+                const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
+                const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
+                c111 += __popc(b111);
+                c110 += __popc(a11 ^ b111);
+                c101 += __popc(b101);
+                c100 += __popc(a10 ^ b101);
+                c011 += __popc(b011);
+                c010 += __popc(a01 ^ b011);
+                c001 += __popc(b001);
+                c000 += __popc(a00 ^ b001);
+            }
+        }
+        const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
+        const bool pass8 = inrange && (float) m8 >= thr;
+        pass = cand == 0 ? pass8 : pass4;
+    }
+    cand |= pass ? (1ull << (k - 1)) : 0ull;
+    // V_{k+1} = V_k & (v1 >> k)
+#pragma unroll
+    for (int j = 0; j < NW; j++)
+        if (j < nww) V[j] &= shr_word<NW, WS>(v1, j, bs);
+}
+
 // Candidate-k mask of one segment (bit k-1).  lo/hi/nm hold the segment's
 // planes from bit 0; L <= 32*NW-1 bases.  gmin..gmax is the wave-uniform k
 // loop (MIN_MER..MAX_MER); only k in [kmin,kmax] can become candidates.
+// max_seg (wave-uniform) bounds L over the whole batch.
+//
+// Soundness: windows of one rotation class (kmer.cpp:1815-1823) have the same
+// base composition, hence the same (#lo-bit, #hi-bit, #A) parities.  With
+// P_b the exclusive prefix parity of feature b, the parity of window i is
+// P_b[i] ^ P_b[i+k]; so the size of every parity bucket is one popcount and the
+// largest bucket is an upper bound of K_MER_DATA_MAX (kmer.cpp:2202).
 template <int NW>
 __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&hi)[NW], const u32 (&nm)[NW], int L,
-                                              int kmin, int kmax, int gmin, int gmax, float lowf) {
-    u32 v1[NW], P1[NW], P2[NW], P3[NW];
+                                              int kmin, int kmax, int gmin, int gmax, int max_seg, float lowf) {
+    u32 v1[NW], P1[NW], P2[NW], P3[NW], V[NW];
     {
         u32 f1[NW], f2[NW], f3[NW];
 #pragma unroll
@@ -130,62 +210,32 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
             f1[j] = lo[j] & v1[j];
             f2[j] = hi[j] & v1[j];
             f3[j] = f1[j] & f2[j];
+            V[j] = v1[j];
         }
         prefix_parity<NW>(f1, P1);
         prefix_parity<NW>(f2, P2);
         prefix_parity<NW>(f3, P3);
     }
-    u32 V[NW], SV[NW], S1[NW], S2[NW], S3[NW];
+    // V = V_gmin: windows of length gmin with no N (kmer.cpp:2190)
+    for (int t = 1; t < gmin && t < 32; t++) {
 #pragma unroll
-    for (int j = 0; j < NW; j++) {
-        V[j] = v1[j];
-        SV[j] = v1[j];
-        S1[j] = P1[j];
-        S2[j] = P2[j];
-        S3[j] = P3[j];
+        for (int j = 0; j < NW; j++) V[j] &= shr_word<NW, 0>(v1, j, (u32) t);
     }
-    // advance to k = gmin:  V = V_gmin (windows with no N, kmer.cpp:2190), S = P >> gmin
-    for (int t = 1; t < gmin; t++) {
-        shr1<NW>(SV);
+    for (int t = 32; t < gmin; t++) {
 #pragma unroll
-        for (int j = 0; j < NW; j++) V[j] &= SV[j];
-    }
-    for (int t = 0; t < gmin; t++) {
-        shr1<NW>(S1);
-        shr1<NW>(S2);
-        shr1<NW>(S3);
+        for (int j = 0; j < NW; j++) V[j] &= shr_word<NW, 1>(v1, j, (u32) t & 31u);
     }
     u64 cand = 0;
-    for (int k = gmin; k <= gmax; k++) {
-        u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0, count = 0;
-#pragma unroll
-        for (int j = 0; j < NW; j++) {
-            const u32 F1 = P1[j] ^ S1[j], F2 = P2[j] ^ S2[j], F3 = P3[j] ^ S3[j];
-            const u32 v = V[j];
-            const u32 a1 = v & F1, a0 = v ^ a1;
-            const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
-            const u32 b111 = a11 & F3, b110 = a11 ^ b111, b101 = a10 & F3, b100 = a10 ^ b101;
-            const u32 b011 = a01 & F3, b010 = a01 ^ b011, b001 = a00 & F3, b000 = a00 ^ b001;
-            count += __popc(v);
-            c000 += __popc(b000);
-            c001 += __popc(b001);
-            c010 += __popc(b010);
-            c011 += __popc(b011);
-            c100 += __popc(b100);
-            c101 += __popc(b101);
-            c110 += __popc(b110);
-            c111 += __popc(b111);
-        }
-        const u32 m = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
-        // sound: MAX <= m, so MAX/COUNT >= LOW needs m >= LOW*COUNT; lowf < LOW*(1-1e-6) absorbs float rounding
-        const bool pass = count != 0u && (float) m >= (float) count * lowf && k >= kmin && k <= kmax;
-        cand |= pass ? (1ull << (k - 1)) : 0ull;
-        shr1<NW>(SV);
-#pragma unroll
-        for (int j = 0; j < NW; j++) V[j] &= SV[j];
-        shr1<NW>(S1);
-        shr1<NW>(S2);
-        shr1<NW>(S3);
+    const int g31 = gmax < 31 ? gmax : 31;
+    for (int k = gmin; k <= g31; k++) {
+        int nww = (max_seg - k + 1 + 31) >> 5;
+        nww = nww < 0 ? 0 : nww;
+        filter_k<NW, 0>(P1, P2, P3, v1, V, k, nww, kmin, kmax, lowf, cand);
+    }
+    for (int k = gmin > 32 ? gmin : 32; k <= gmax; k++) {
+        int nww = (max_seg - k + 1 + 31) >> 5;
+        nww = nww < 0 ? 0 : nww;
+        filter_k<NW, 1>(P1, P2, P3, v1, V, k, nww, kmin, kmax, lowf, cand);
     }
     return cand;
 }
@@ -199,7 +249,7 @@ __device__ __forceinline__ u64 all_k_mask(int kmin, int kmax) {
 
 template <int NW>
 __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, WorkItem *wl, u32 *wl_count, u32 wl_cap,
-                                                     u64 *dbg_masks, int dbg_slots) {
+                                                     u64 *dbg_masks, int dbg_slots, int max_seg) {
     const u64 unit = (u64) blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = unit < B.n_units;
     ReadRef rd[2];
@@ -240,7 +290,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, Wo
                 if (P.flags & TREW_FLAG_NO_FILTER)
                     m = all_k_mask(sg.kmin, sg.kmax);
                 else
-                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer, P.max_mer, P.lowf);
+                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer, P.max_mer, max_seg, P.lowf);
                 masks[slot] = ok ? m : 0ull;
             }
             // a segment too long for this instantiation must never be dropped silently
@@ -286,7 +336,7 @@ __device__ __forceinline__ u64 hash64(u64 x) {
     return x;
 }
 
-__device__ void table_add(const DevTable &T, int table, int k, u64 word, u64 cnt) {
+__attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k, u64 word, u64 cnt) {
     if (T.log2_part_slots == 0xffffffffu) return;  // TREW_FLAG_DEBUG_NO_EMIT (timing experiments only)
     const u32 part = (u32) (word & ((1u << kTablePartBits) - 1u));
     const u64 key = (1ull << 63) | ((u64) table << 60) | ((u64) (k - 1) << 55) | (word >> kTablePartBits);
@@ -316,15 +366,17 @@ __device__ void table_add(const DevTable &T, int table, int k, u64 word, u64 cnt
 // LDS working set of one wave, carved from dynamic LDS and sized by the longest
 // segment of the batch (cap bases, a multiple of 64): 2.6 KB for 150-bp reads, so
 // 8 waves per SIMD stay resident and hide the global/LDS latency chains.
+// The struct only carries the two sizes (it travels in SGPRs); every array is an
+// offset from the dynamic-LDS base so that accesses compile to ds_* instructions.
+//   seq   [cap/32+2] u64  2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
+//   canon [cap]      u64  per run (fast path) or per window (fallback)
+//   vmask [cap/64+2] u64  bit i: window i has no N
+//   emask [cap/64+2] u64  bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
+//   nmask [cap/32+2] u32  bit i = base i is not A/C/G/T or lies past the segment end
+//   raw   [2][rawwords] u32  the unit's packed triples, staged once
+//   cnt   [cap] u16  class size at the class's first item, else 0
+//   start [cap] u16  first window of each run
 struct ExactSmem {
-    u64 *seq;     // [cap/32+2] 2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
-    u64 *canon;   // [cap] per run (fast path) or per window (fallback)
-    u64 *vmask;   // [cap/64+2] bit i: window i has no N
-    u64 *emask;   // [cap/64+2] bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
-    u32 *nmask;   // [cap/32+2] bit i = base i is not A/C/G/T or lies past the segment end
-    u32 *raw;     // [2][rawwords] the unit's packed triples, staged once
-    unsigned short *cnt;    // [cap] class size at the class's first item, else 0
-    unsigned short *start;  // [cap] first window of each run
     u32 cap, rawwords;
 };
 
@@ -332,18 +384,18 @@ __host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords) {
     return (cap / 32 + 2) * 8 + cap * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 16;
 }
 
-__device__ inline void carve_smem(ExactSmem &sm, unsigned char *base, u32 cap, u32 rawwords) {
-    sm.cap = cap;
-    sm.rawwords = rawwords;
-    sm.seq = (u64 *) base;
-    sm.canon = sm.seq + (cap / 32 + 2);
-    sm.vmask = sm.canon + cap;
-    sm.emask = sm.vmask + (cap / 64 + 2);
-    sm.nmask = (u32 *) (sm.emask + (cap / 64 + 2));
-    sm.raw = sm.nmask + (cap / 32 + 2);
-    sm.cnt = (unsigned short *) (sm.raw + 2 * rawwords);
-    sm.start = sm.cnt + cap;
+__device__ __forceinline__ unsigned char *lds0() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char trew_lds[];
+    return trew_lds;
 }
+__device__ __forceinline__ u64 *sm_seq(ExactSmem sm) { return (u64 *) lds0(); }
+__device__ __forceinline__ u64 *sm_canon(ExactSmem sm) { return sm_seq(sm) + (sm.cap / 32 + 2); }
+__device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_canon(sm) + sm.cap; }
+__device__ __forceinline__ u64 *sm_emask(ExactSmem sm) { return sm_vmask(sm) + (sm.cap / 64 + 2); }
+__device__ __forceinline__ u32 *sm_nmask(ExactSmem sm) { return (u32 *) (sm_emask(sm) + (sm.cap / 64 + 2)); }
+__device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm.cap / 32 + 2); }
+__device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 2 * sm.rawwords); }
+__device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
 
 __device__ __forceinline__ u64 spread32(u32 v) {
     u64 x = v;
@@ -357,8 +409,8 @@ __device__ __forceinline__ u64 spread32(u32 v) {
 
 // stage bases [s, s+L) of a read into LDS (one wave)
 // copy a read's triples into LDS once; later segment staging reads LDS, not HBM
-__device__ ReadRef stage_read(ExactSmem &sm, const ReadRef &rd, int mate) {
-    u32 *dst = sm.raw + (u32) mate * sm.rawwords;
+__device__ ReadRef stage_read(ExactSmem sm, const ReadRef &rd, int mate) {
+    u32 *dst = sm_raw(sm) + (u32) mate * sm.rawwords;
     const u32 n = 3u * rd.nw;
     if (n > sm.rawwords) return rd;  // does not fit (long mode): keep reading global memory
     for (u32 j = lane_id(); j < n; j += 64) dst[j] = rd.w[j];
@@ -367,7 +419,7 @@ __device__ ReadRef stage_read(ExactSmem &sm, const ReadRef &rd, int mate) {
     return r;
 }
 
-__device__ void load_segment(ExactSmem &sm, const ReadRef &rd, u32 s, u32 L) {
+__attribute__((noinline)) __device__ void load_segment(ExactSmem sm, const ReadRef &rd, u32 s, u32 L) {
     __syncthreads();
     const u32 nwords = (L + 31u) >> 5;
     const u32 segwords = sm.cap / 32 + 2;
@@ -383,8 +435,8 @@ __device__ void load_segment(ExactSmem &sm, const ReadRef &rd, u32 s, u32 L) {
             const u32 l = lo[0] & ~nmv, h = hi[0] & ~nmv;
             sq = spread32(__brev(l)) | (spread32(__brev(h)) << 1);
         }
-        sm.seq[lane] = sq;
-        sm.nmask[lane] = nmv;
+        sm_seq(sm)[lane] = sq;
+        sm_nmask(sm)[lane] = nmv;
     }
     __syncthreads();
 }
@@ -431,18 +483,18 @@ struct KStat {
     bool pruned; // the bucket bound proved MAX/COUNT < need: maxc/maxseq were not computed
 };
 
-__device__ __forceinline__ u32 base_at(const ExactSmem &sm, u32 p) {
-    return (u32) (sm.seq[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
+__device__ __forceinline__ u32 base_at(ExactSmem sm, u32 p) {
+    return (u32) (sm_seq(sm)[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
 }
-__device__ __forceinline__ u64 window_word(const ExactSmem &sm, u32 i, int k) {
+__device__ __forceinline__ u64 window_word(ExactSmem sm, u32 i, int k) {
     const u32 wi = i >> 5, sh = 2u * (i & 31u);
-    const u64 a = sm.seq[wi], b = sm.seq[wi + 1];
+    const u64 a = sm_seq(sm)[wi], b = sm_seq(sm)[wi + 1];
     const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
     return x >> (64 - 2 * k);
 }
-__device__ __forceinline__ bool window_valid(const ExactSmem &sm, u32 i, int k) {
+__device__ __forceinline__ bool window_valid(ExactSmem sm, u32 i, int k) {
     const u32 wi = i >> 5, bi = i & 31u;
-    const u64 nmw = (((u64) sm.nmask[wi + 1] << 32) | sm.nmask[wi]) >> bi;
+    const u64 nmw = (((u64) sm_nmask(sm)[wi + 1] << 32) | sm_nmask(sm)[wi]) >> bi;
     return (nmw & ((1ull << k) - 1ull)) == 0;  // no N inside the window (kmer.cpp:2190)
 }
 
@@ -463,15 +515,15 @@ __device__ __forceinline__ void wave_best(u32 best, u64 best_seq, KStat &st) {
 
 // Fallback for segments with more than 64 runs: one item per window, class sizes
 // by an all-pairs LDS-broadcast compare.  vmask[] must hold the valid-window bits.
-__device__ void eval_k_windows(ExactSmem &sm, int W, int k, KStat &st) {
+__attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, int k, KStat &st) {
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
         if (i < W) {
-            const bool valid = (sm.vmask[r] >> lane) & 1ull;
-            sm.canon[i] = valid ? min_rotation(window_word(sm, (u32) i, k), k) : 0ull;
-            sm.cnt[i] = 0;
+            const bool valid = (sm_vmask(sm)[r] >> lane) & 1ull;
+            sm_canon(sm)[i] = valid ? min_rotation(window_word(sm, (u32) i, k), k) : 0ull;
+            sm_cnt(sm)[i] = 0;
         }
     }
     __syncthreads();
@@ -479,24 +531,24 @@ __device__ void eval_k_windows(ExactSmem &sm, int W, int k, KStat &st) {
     u64 best_seq = 0;
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
-        const bool mine = i < W && ((sm.vmask[r] >> lane) & 1ull);
-        const u64 my = mine ? sm.canon[i] : 0;
+        const bool mine = i < W && ((sm_vmask(sm)[r] >> lane) & 1ull);
+        const u64 my = mine ? sm_canon(sm)[i] : 0;
         u32 c = 0, last = 0;
         bool first = true;
         for (int jr = 0; jr < rounds; jr++) {
-            u64 vm = rfl64(sm.vmask[jr]);
+            u64 vm = rfl64(sm_vmask(sm)[jr]);
             while (vm) {
                 const int jb = __ffsll((long long) vm) - 1;
                 vm &= vm - 1;
                 const int j = jr * 64 + jb;
-                const bool eq = sm.canon[j] == my;  // LDS broadcast read
+                const bool eq = sm_canon(sm)[j] == my;  // LDS broadcast read
                 c += eq ? 1u : 0u;
                 last = eq ? (u32) j : last;
                 first = first && !(eq && j < i);
             }
         }
         if (mine) {
-            if (first) sm.cnt[i] = (unsigned short) c;
+            if (first) sm_cnt(sm)[i] = (unsigned short) c;
             const u32 key = (c << 16) | (0xffffu - last);
             if (key > best) {
                 best = key;
@@ -521,7 +573,7 @@ __device__ void eval_k_windows(ExactSmem &sm, int W, int k, KStat &st) {
 // bounds MAX from above; if even that bound gives a frequency below `need`
 // (the smallest threshold this k still has to reach in decide()), the k cannot
 // be accepted and the per-run canonicalisation is skipped (st.pruned).
-__device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
+__attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, double need) {
     KStat st;
     st.count = 0;
     st.maxc = 0;
@@ -548,8 +600,8 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
         }
         const u64 bv = __ballot(valid), be = __ballot(eq);
         if (lane == 0) {
-            sm.vmask[r] = bv;
-            sm.emask[r] = be;
+            sm_vmask(sm)[r] = bv;
+            sm_emask(sm)[r] = be;
         }
         if (need > 0.0) {
             const u64 f1 = __ballot(p1), f2 = __ballot(p2), f3 = __ballot(p3);
@@ -567,13 +619,13 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
         }
     }
     if (lane == 0) {
-        sm.vmask[rounds] = 0;
-        sm.emask[rounds] = 0;
+        sm_vmask(sm)[rounds] = 0;
+        sm_emask(sm)[rounds] = 0;
     }
     __syncthreads();
     if (need > 0.0) {
         u32 cnt = 0;
-        for (int r = 0; r < rounds; r++) cnt += (u32) __popcll(rfl64(sm.vmask[r]));
+        for (int r = 0; r < rounds; r++) cnt += (u32) __popcll(rfl64(sm_vmask(sm)[r]));
         const u32 mb = max(max(max(b0, b1), max(b2, b3)), max(max(b4, b5), max(b6, b7)));
         // MAX <= mb and IEEE division is monotone in the numerator, so MAX/COUNT <= mb/COUNT < need
         if (cnt == 0 || (double) rfl(mb) / (double) cnt < need) {
@@ -587,12 +639,12 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
     u32 R = 0, count = 0;
     u64 carry = 0;
     for (int r = 0; r < rounds; r++) {
-        const u64 vm = rfl64(sm.vmask[r]), em = rfl64(sm.emask[r]);
+        const u64 vm = rfl64(sm_vmask(sm)[r]), em = rfl64(sm_emask(sm)[r]);
         const u64 ve = vm & em;
         const u64 startmask = vm & ~((ve << 1) | carry);
         carry = ve >> 63;
         count += (u32) __popcll(vm);
-        if ((startmask >> lane) & 1ull) sm.start[R + (u32) __popcll(startmask & ((1ull << lane) - 1ull))] = (unsigned short) (r * 64 + (int) lane);
+        if ((startmask >> lane) & 1ull) sm_start(sm)[R + (u32) __popcll(startmask & ((1ull << lane) - 1ull))] = (unsigned short) (r * 64 + (int) lane);
         R += (u32) __popcll(startmask);
     }
     st.count = count;
@@ -606,14 +658,14 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
     u64 canon = ~0ull;
     u32 len = 0, s = 0;
     if (lane < R) {
-        s = sm.start[lane];
+        s = sm_start(sm)[lane];
         // run length = 1 + number of consecutive j >= s with valid_j && eq_j && valid_{j+1}
         u32 j = s;
         len = 1;
         for (;;) {
             const u32 wi = j >> 6, bi = j & 63u;
-            const u64 v0 = sm.vmask[wi], v1 = sm.vmask[wi + 1];
-            const u64 cw = (v0 & sm.emask[wi] & ((v0 >> 1) | (v1 << 63))) >> bi;
+            const u64 v0 = sm_vmask(sm)[wi], v1 = sm_vmask(sm)[wi + 1];
+            const u64 cw = (v0 & sm_emask(sm)[wi] & ((v0 >> 1) | (v1 << 63))) >> bi;
             const u64 inv = ~cw;
             const u32 ones = inv ? (u32) (__ffsll((long long) inv) - 1) : 64u;
             len += ones;
@@ -640,8 +692,8 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
     u32 key = 0;
     if (lane < R) {
         key = (tot << 16) | (0xffffu - last);
-        sm.canon[lane] = canon;
-        sm.cnt[lane] = first ? (unsigned short) tot : (unsigned short) 0;
+        sm_canon(sm)[lane] = canon;
+        sm_cnt(sm)[lane] = first ? (unsigned short) tot : (unsigned short) 0;
     }
     wave_best(key, canon, st);
     st.n_items = R;
@@ -652,12 +704,12 @@ __device__ KStat eval_k(ExactSmem &sm, int L, int k, double need) {
 // add every class of the k just evaluated to the tables in table_mask (bit t).
 // strand_canon: key = MIN(w, rot(rc(w))) (k_mer_target, kmer.cpp:1979-1988) else the
 // rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
-__device__ void emit_k(ExactSmem &sm, const DevTable &T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
+__attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
     const u32 lane = lane_id();
     for (u32 i = lane; i < n_items; i += 64) {
-        const u32 c = sm.cnt[i];
+        const u32 c = sm_cnt(sm)[i];
         if (c) {
-            u64 w = sm.canon[i];
+            u64 w = sm_canon(sm)[i];
             if (strand_canon) {
                 const u64 rc = min_rotation(revcomp(w, k), k);
                 w = rc < w ? rc : w;
@@ -665,6 +717,97 @@ __device__ void emit_k(ExactSmem &sm, const DevTable &T, u32 n_items, int k, u32
             for (u32 tm = table_mask; tm; tm &= tm - 1) table_add(T, __ffs((int) tm) - 1, k, w, c);
         }
     }
+}
+
+// per-lane variable right shift of a multiword mask by off in [0, 63]
+template <int NW>
+__device__ __forceinline__ u32 shr_var_word(const u32 (&x)[NW], int j, u32 off) {
+    const bool big = off >= 32u;
+    const u32 x0 = x[j], x1 = j + 1 < NW ? x[j + 1 < NW ? j + 1 : 0] : 0u, x2 = j + 2 < NW ? x[j + 2 < NW ? j + 2 : 0] : 0u;
+    return alignbit(big ? x2 : x1, big ? x1 : x0, off & 31u);
+}
+
+// Upper bound of MAX/COUNT for EVERY k of one segment at once: lane l handles
+// k = gmin + l with the same bit-parallel parity-bucket bound as the prefilter
+// (filter_segment), the shift amounts simply differ per lane.  Used by decide()
+// to discard a candidate k with one readlane instead of a pass over its windows.
+// Returns (double) maxbucket / (double) count, 0 where there is no valid window.
+template <int NW>
+__attribute__((noinline)) __device__ double lane_bounds(const ReadRef &rd, u32 s, int L, int gmin, int gmax) {
+    u32 lo[NW], hi[NW], nm[NW];
+    load_planes<NW>(rd, s, lo, hi, nm);  // every lane reads the same (LDS-staged) words
+    u32 v1[NW], P1[NW], P2[NW], P3[NW];
+    {
+        u32 f1[NW], f2[NW], f3[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            int bits = L - 32 * j;
+            u32 lm = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+            v1[j] = ~nm[j] & lm;
+            f1[j] = lo[j] & v1[j];
+            f2[j] = hi[j] & v1[j];
+            f3[j] = f1[j] & f2[j];
+        }
+        prefix_parity<NW>(f1, P1);
+        prefix_parity<NW>(f2, P2);
+        prefix_parity<NW>(f3, P3);
+    }
+    const int k = gmin + (int) lane_id();
+    const u32 ku = (u32) k;
+    // V_k[i] = AND_{t<k} v1[i+t] by binary decomposition of k over A_b = AND of b consecutive bases
+    u32 V[NW], A[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        V[j] = 0xffffffffu;
+        A[j] = v1[j];
+    }
+    u32 off = 0;
+#pragma unroll
+    for (int b = 1; b <= 64; b <<= 1) {
+        if (b > 1) {  // A_b = A_{b/2} & (A_{b/2} >> b/2)
+            u32 T2[NW];
+#pragma unroll
+            for (int j = 0; j < NW; j++) T2[j] = A[j] & shr_var_word<NW>(A, j, (u32) (b / 2));
+#pragma unroll
+            for (int j = 0; j < NW; j++) A[j] = T2[j];
+        }
+        if (b <= gmax) {  // wave-uniform
+            const bool take = (ku & (u32) b) != 0;
+#pragma unroll
+            for (int j = 0; j < NW; j++) {
+                const u32 sh = shr_var_word<NW>(A, j, off);
+                V[j] &= take ? sh : 0xffffffffu;
+            }
+            off += take ? (u32) b : 0u;
+        }
+    }
+    u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0, count = 0;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        const u32 F1 = P1[j] ^ shr_var_word<NW>(P1, j, ku), F2 = P2[j] ^ shr_var_word<NW>(P2, j, ku);
+        const u32 F3 = P3[j] ^ shr_var_word<NW>(P3, j, ku);
+        const u32 v = V[j];
+        const u32 a1 = v & F1, a0 = v ^ a1;
+        const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
+        const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
+        count += __popc(v);
+        c111 += __popc(b111);
+        c110 += __popc(a11 ^ b111);
+        c101 += __popc(b101);
+        c100 += __popc(a10 ^ b101);
+        c011 += __popc(b011);
+        c010 += __popc(a01 ^ b011);
+        c001 += __popc(b001);
+        c000 += __popc(a00 ^ b001);
+    }
+    const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
+    if (k > gmax || k >= 64 || count == 0) return k >= 64 && k <= gmax ? 2.0 : 0.0;  // k = 64 is not bounded here: never prune it
+    return (double) m8 / (double) count;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
 }
 
 struct Decision {
@@ -683,7 +826,9 @@ __device__ __forceinline__ bool divides_any(int k, u64 accepted) {
 
 // selection loops of k_mer_check, kmer.cpp:2221-2258, run online over ascending
 // candidate k (non-candidates have frequency < LOW and can never be accepted)
-__device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, int kmax, u64 cand) {
+// ub: per-lane bound of lane_bounds() (lane l <-> k = MIN_MER + l), or NaN-free negative value "no bounds"
+template <bool HAVE_UB>
+__device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, double ub) {
     Decision d;
     d.kh = d.kl = 0;
     d.sh = d.sl = 0;
@@ -698,7 +843,11 @@ __device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, i
         const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
         const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
-        const KStat st = eval_k(sm, L, k, need);
+        if (HAVE_UB) {
+            // MAX <= maxbucket and IEEE division is monotone in the numerator: f <= bound < need
+            if (readlane_f64(ub, k - P.min_mer) < need) continue;
+        }
+        const KStat st = eval_k(sm, L, k, HAVE_UB ? 0.0 : need);
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
         if (is_homopolymer(st.maxseq, k)) continue;
@@ -719,14 +868,14 @@ __device__ Decision decide(ExactSmem &sm, const DevParams &P, int L, int kmin, i
 }
 
 // record the histogram of segment (already staged) at k into tables
-__device__ void record(ExactSmem &sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
+__device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
     if (k <= 0 || table_mask == 0) return;
     const KStat st = eval_k(sm, L, k, 0.0);
     emit_k(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
 // k_mer_target, kmer.cpp:1894-2017, on the staged whole read
-__device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
+__device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
     const KStat st = eval_k(sm, L, k, 0.0);
     if (st.count == 0) return;
     const double f = is_homopolymer(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
@@ -737,7 +886,10 @@ __device__ void target(ExactSmem &sm, const DevParams &P, const DevTable &T, int
 }
 
 // buffer_task, kmer.cpp:111-173
-__device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+template <int NW>
+__device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+    constexpr bool UB = NW > 0;
+    constexpr int NWB = NW > 0 ? NW : 1;
     const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
     const int n = (int) rd.len;
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
@@ -746,9 +898,14 @@ __device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, 
     Decision left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
     if (sL.valid) {
         load_segment(sm, rd, sL.start, sL.len);
-        left = decide(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0]);
+        double ubL = 0, ubR = 0;
+        if (UB) {
+            ubL = lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer);
+            ubR = lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer);
+        }
+        left = decide<UB>(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0], ubL);
         load_segment(sm, rd, sR.start, sR.len);
-        right = decide(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1]);
+        right = decide<UB>(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1], ubR);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
@@ -792,7 +949,8 @@ __device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, 
     const bool lh = left.kl == 0 && right.kl == 0;
     if (sW.valid && (hh || lh)) {  // kmer.cpp:168-171
         load_segment(sm, rd, 0, (u32) n);
-        const Decision w = decide(sm, P, n, sW.kmin, sW.kmax, it.cand[2]);
+        const double ubW = UB ? lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer) : 0.0;
+        const Decision w = decide<UB>(sm, P, n, sW.kmin, sW.kmax, it.cand[2], ubW);
         const bool rec_h = hh && w.kh > 0, rec_l = lh && w.kl > 0;
         if (rec_h && rec_l && w.kh == w.kl) {
             record(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
@@ -804,13 +962,17 @@ __device__ void run_short(ExactSmem &sm, const DevParams &P, const DevBatch &B, 
 }
 
 // TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
-__device__ void run_segment(ExactSmem &sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it,
+template <int NW>
+__device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it,
                             const SegResults &R) {
+    constexpr bool UB = NW > 0;
+    constexpr int NWB = NW > 0 ? NW : 1;
     const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
     load_segment(sm, rd, 0, s.len);
-    const Decision d = decide(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0]);
+    const double ub = UB ? lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer) : 0.0;
+    const Decision d = decide<UB>(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0], ub);
     if (d.kh > 0 && d.kh == d.kl) {
         record(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
     } else {
@@ -825,19 +987,22 @@ __device__ void run_segment(ExactSmem &sm, const DevParams &P, const DevBatch &B
     }
 }
 
+// NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
+// NW == 0: long segments, pruning happens inside eval_k instead.
+template <int NW>
 __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
                                                    const u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     ExactSmem sm;
-    carve_smem(sm, lds_raw, cap, rawwords);
+    sm.cap = cap;
+    sm.rawwords = rawwords;
     u32 n = *wl_count;
     n = n < wl_cap ? n : wl_cap;
     for (u32 w = blockIdx.x; w < n; w += gridDim.x) {
         const WorkItem it = wl[w];
         if (P.mode == TREW_MODE_SHORT)
-            run_short(sm, P, B, T, it);
+            run_short<NW>(sm, P, B, T, it);
         else if (P.mode == TREW_MODE_SEGMENT)
-            run_segment(sm, P, B, T, it, R);
+            run_segment<NW>(sm, P, B, T, it, R);
         __syncthreads();
     }
 }
@@ -929,18 +1094,20 @@ int pick_nw(u32 max_seg_len) {
     return 32;
 }
 
-hipError_t launch_filter(hipStream_t st, int nw, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
+hipError_t launch_filter(hipStream_t st, u32 max_seg_len, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
                          u32 wl_cap, u64 *dbg_masks, int dbg_slots) {
+    const int nw = pick_nw(max_seg_len);
+    const int max_seg = (int) std::min<u32>(max_seg_len, (u32) (32 * nw - 1));
     if (B.n_units == 0) return hipSuccess;
     const u32 threads = 256;
     const u64 blocks = (B.n_units + threads - 1) / threads;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     dim3 g((u32) blocks), b(threads);
     switch (nw) {
-    case 3: hipLaunchKernelGGL(filter_kernel<3>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
-    case 5: hipLaunchKernelGGL(filter_kernel<5>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
-    case 10: hipLaunchKernelGGL(filter_kernel<10>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
-    default: hipLaunchKernelGGL(filter_kernel<32>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots); break;
+    case 3: hipLaunchKernelGGL(filter_kernel<3>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
+    case 5: hipLaunchKernelGGL(filter_kernel<5>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
+    case 10: hipLaunchKernelGGL(filter_kernel<10>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
+    default: hipLaunchKernelGGL(filter_kernel<32>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
     }
     return hipGetLastError();
 }
@@ -949,8 +1116,15 @@ u32 exact_lds_bytes_host(u32 cap, u32 rawwords) { return exact_lds_bytes(cap, ra
 
 hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
                         const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords) {
-    hipLaunchKernelGGL(exact_kernel, dim3(grid), dim3(64), exact_lds_bytes(cap, rawwords), st, P, B, T, wl, wl_count, wl_cap, R, cap,
-                       rawwords);
+    // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
+    const u32 lds = exact_lds_bytes(cap, rawwords);
+    const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (cap - 1 <= 95 ? 3 : cap - 1 <= 159 ? 5 : cap - 1 <= 319 ? 10 : 0);
+    switch (nw) {
+    case 3: hipLaunchKernelGGL(exact_kernel<3>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
+    case 5: hipLaunchKernelGGL(exact_kernel<5>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
+    case 10: hipLaunchKernelGGL(exact_kernel<10>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
+    default: hipLaunchKernelGGL(exact_kernel<0>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
+    }
     return hipGetLastError();
 }
 

@@ -8,7 +8,7 @@ namespace trew {
 
 int pick_nw(u32 max_seg_len);
 
-hipError_t launch_filter(hipStream_t st, int nw, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
+hipError_t launch_filter(hipStream_t st, u32 max_seg_len, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
                          u32 wl_cap, u64 *dbg_masks, int dbg_slots);
 hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
                         const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords);
