@@ -143,7 +143,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         if ((e = hipMalloc((void **) &s.d_offsets, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(offsets)", e);
         if ((e = hipMalloc((void **) &s.d_lengths, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(lengths)", e);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(WorkItem))) != hipSuccess) return bail("hipMalloc(worklist)", e);
-        if ((e = hipMalloc((void **) &s.d_wl_count, 4)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
+        if ((e = hipMalloc((void **) &s.d_wl_count, 8)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
         if (p.mode == TREW_MODE_SEGMENT) {
             if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
@@ -277,7 +277,7 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     s.n_units = db.n_units;
     s.timed = false;
     if (db.n_units == 0) return 0;
-    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, 4, s.stream));
+    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, 8, s.stream));
     if (ctx->p.mode == TREW_MODE_SEGMENT) {
         HIPCHK(ctx, hipMemsetAsync(s.res.k_high, 0, db.n_reads * 4, s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.res.k_low, 0, db.n_reads * 4, s.stream));
@@ -293,12 +293,9 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
     const u32 cap = std::max<u32>(64u, ((exact_seg + 1 + 63u) / 64u) * 64u);
     const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
-    const u32 lds = exact_lds_bytes_host(cap, rawwords);
-    const u32 waves_per_cu = std::max<u32>(1u, std::min<u32>(32u, (160u * 1024u) / lds));
-    const u32 grid = (u32) std::min<u64>((u64) ctx->n_cu * waves_per_cu, std::max<u64>(db.n_units, 1));
     DevTable tbl = ctx->table;
     if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
-    HIPCHK(ctx, launch_exact(s.stream, grid, ctx->dp, db, tbl, s.d_wl, s.d_wl_count, wl_cap, s.res, cap, rawwords));
+    HIPCHK(ctx, launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, s.d_wl_count, wl_cap, s.res, cap, rawwords, max_seg));
     HIPCHK(ctx, hipEventRecord(s.e2, s.stream));
     s.timed = true;
     return 0;
@@ -401,7 +398,7 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     const u64 bytes = db.n_units * (u64) slots_per_read * 8ull;
     HIPCHK(ctx, hipMalloc((void **) &d, bytes));
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
-    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 4, s.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 8, s.stream);
     if (e == hipSuccess)
         e = launch_filter(s.stream, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);

@@ -991,13 +991,19 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B,
 // NW == 0: long segments, pruning happens inside eval_k instead.
 template <int NW>
 __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
-                                                   const u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
+                                                   u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
     ExactSmem sm;
     sm.cap = cap;
     sm.rawwords = rawwords;
-    u32 n = *wl_count;
+    u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
-    for (u32 w = blockIdx.x; w < n; w += gridDim.x) {
+    // dynamic self-scheduling: reads differ 10x in cost, so waves pull the next item from a
+    // device counter (wl_count[1], zeroed with wl_count[0]) instead of a static stride
+    for (;;) {
+        u32 w = 0;
+        if (lane_id() == 0) w = atomicAdd(&wl_count[1], 1u);
+        w = rfl(w);
+        if (w >= n) break;
         const WorkItem it = wl[w];
         if (P.mode == TREW_MODE_SHORT)
             run_short<NW>(sm, P, B, T, it);
@@ -1114,11 +1120,20 @@ hipError_t launch_filter(hipStream_t st, u32 max_seg_len, const DevParams &P, co
 
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords) { return exact_lds_bytes(cap, rawwords); }
 
-hipError_t launch_exact(hipStream_t st, u32 grid, const DevParams &P, const DevBatch &B, const DevTable &T,
-                        const WorkItem *wl, const u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords) {
+hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
+                        const WorkItem *wl, u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
+                        u32 max_seg_len) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
     const u32 lds = exact_lds_bytes(cap, rawwords);
-    const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (cap - 1 <= 95 ? 3 : cap - 1 <= 159 ? 5 : cap - 1 <= 319 ? 10 : 0);
+    // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
+    const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
+    // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
+    int per_cu = 8;
+    const void *fn = nw == 3 ? (const void *) exact_kernel<3> : nw == 5 ? (const void *) exact_kernel<5>
+                   : nw == 10 ? (const void *) exact_kernel<10> : (const void *) exact_kernel<0>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    per_cu = per_cu > 32 ? 32 : per_cu;
+    const u32 grid = (u32) std::min<u64>((u64) n_cu * (u64) per_cu, std::max<u64>(n_units, 1));
     switch (nw) {
     case 3: hipLaunchKernelGGL(exact_kernel<3>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
     case 5: hipLaunchKernelGGL(exact_kernel<5>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
