@@ -192,3 +192,120 @@ def test_empty_and_tiny_batches():
     with pytest.raises(T.TrewHipError):
         with T.TrewHip(mode=T.MODE_SHORT) as t:
             t.submit_reads([b"A" * 1001])
+
+
+# ---------------------------------------------------------------- paired-end (buffer_task_pair)
+def _pair_parity(r1, r2, **kw):
+    p = O.OracleParams(**{k: v for k, v in kw.items() if k in ("min_mer", "max_mer", "low", "high")})
+    want = O.run_pair(p, r1, r2)
+    reads = []
+    for a, b in zip(r1, r2):
+        reads += [a, b]
+    with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, **kw) as t:
+        t.submit_reads(reads)
+        t.wait()
+        got = t.collect()
+    for name in T.TABLE_NAMES:
+        assert got[name] == want[name], name
+    return want
+
+
+def test_pair_parity_synthetic_2x150():
+    b1, b2, st, nd = capi.synth_pair_ascii(20250218, 0, 20000, 150)
+    r1 = [b1[s:e + 1] for s, e in zip(st, nd)]
+    r2 = [b2[s:e + 1] for s, e in zip(st, nd)]
+    want = _pair_parity(r1, r2)
+    assert sum(want["both_high"].values()) > 10000 and len(want["forward_high"]) > 0
+
+
+def _revcomp(s):
+    return s.translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1]
+
+
+def test_pair_parity_edge_pairs():
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(17)
+    r1, r2 = [], []
+    units = ["TTAGGG", "CCCTAA", "AT", "TTAGG", "TTTAGGG", "ACGTACGTAC", "TTGCATCACACCCTCGCCG", "AATT", "A"]
+    for n1, n2 in [(150, 150), (100, 100), (60, 60), (150, 100), (101, 151), (127, 128), (128, 127), (40, 40), (20, 21),
+                   (12, 30), (9, 9), (250, 250), (300, 90)]:
+        for u in units:
+            frag = periodic(u, n1 + n2, rnd.randint(0, 5))
+            frag = mutate(frag, rnd, p_sub=rnd.choice([0.0, 0.01, 0.04]), p_n=rnd.choice([0.0, 0.0, 0.01]))
+            a = frag[:n1].encode()
+            b = _revcomp(frag[n1:].encode())
+            r1.append(a)
+            r2.append(b)
+            # only one mate repetitive / repeat on part of the fragment
+            rand = "".join(rnd.choice("ACGT") for _ in range(n2)).encode()
+            r1.append(a)
+            r2.append(rand)
+            r1.append(_revcomp(rand)[:n1].ljust(n1, b"A")[:n1])
+            r2.append(b)
+            h = (n1 + n2) // 3
+            frag2 = (periodic(u, h) + "".join(rnd.choice("ACGT") for _ in range(n1 + n2 - h)))
+            r1.append(frag2[:n1].encode())
+            r2.append(_revcomp(frag2[n1:].encode()))
+            # different motifs on the two mates
+            r1.append(periodic(u, n1).encode())
+            r2.append(periodic("GGGTTA", n2).encode())
+    want = _pair_parity(r1, r2)
+    assert all(len(want[n]) > 0 for n in T.TABLE_NAMES)
+    _pair_parity(r1, r2, min_mer=3, max_mer=12)
+
+
+# ---------------------------------------------------------------- long reads (buffer_task_long)
+def _long_reads(seed, count):
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(seed)
+    out = []
+    for i in range(count):
+        n = rnd.choice([100, 149, 150, 151, 299, 300, 301, 449, 450, 600, 1000, 1499, 2300, 5000, 12000])
+        body = "".join(rnd.choice("ACGT") for _ in range(n))
+        kind = rnd.random()
+        unit = rnd.choice(["TTAGGG", "CCCTAA", "TTAGGG", "TTTAGGG", "AT", "TTAGGGTTAGGC", "ACG"])
+        if kind < 0.3:
+            t = min(n, rnd.choice([150, 300, 450, 700, 2000]) + rnd.randint(-40, 40))
+            body = body[: n - t] + mutate(periodic(unit, t, rnd.randint(0, 5)), rnd, p_sub=rnd.choice([0.0, 0.02, 0.05]))
+        elif kind < 0.55:
+            t = min(n, rnd.choice([150, 300, 450, 700, 2000]) + rnd.randint(-40, 40))
+            body = mutate(periodic(unit, t, rnd.randint(0, 5)), rnd, p_sub=rnd.choice([0.0, 0.02, 0.05])) + body[t:]
+        elif kind < 0.7:
+            body = mutate(periodic(unit, n, rnd.randint(0, 5)), rnd, p_sub=rnd.choice([0.0, 0.03]), p_n=rnd.choice([0, 0.002]))
+        elif kind < 0.8:
+            # repeat at both ends with different motifs, or a switch of motif inside the repeat
+            t = min(n // 2, 400)
+            body = periodic(unit, t) + body[t: n - t] + periodic("GGGTTA" if rnd.random() < 0.5 else "TTAGG", t)
+        out.append(body[:n].encode())
+    return out
+
+
+@pytest.mark.parametrize("slice_length", [150, 100])
+def test_long_parity(slice_length):
+    reads = _long_reads(31, 400)
+    p = O.OracleParams(slice_len=slice_length)
+    want = O.run_long(p, reads)
+    kept = [r for r in reads if len(r) >= slice_length]
+    with T.TrewHip(mode=T.MODE_LONG, slice_length=slice_length, max_batch_reads=len(kept) + 8, max_batch_words=1 << 22) as t:
+        t.submit_reads(kept)
+        t.wait()
+        got = t.collect()
+    for name in T.TABLE_NAMES:
+        assert got[name] == want[name], name
+    assert all(len(want[n]) > 0 for n in T.TABLE_NAMES)
+
+
+def test_long_fixture_is_empty():
+    reads = read_fastq(os.path.join(GOLDEN, "test_long.fastq"))
+    with T.TrewHip(mode=T.MODE_LONG, max_batch_reads=64, max_batch_words=1 << 20) as t:
+        t.submit_reads(reads)
+        t.wait()
+        got = t.collect()
+    assert all(len(v) == 0 for v in got.values())
+    assert got == O.run_long(O.OracleParams(), reads)

@@ -376,12 +376,13 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
 //   raw   [2][rawwords] u32  the unit's packed triples, staged once
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
+//   intent [32] u32  deferred histogram emissions of the pair driver
 struct ExactSmem {
     u32 cap, rawwords;
 };
 
 __host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords) {
-    return (cap / 32 + 2) * 8 + cap * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 16;
+    return (cap / 32 + 2) * 8 + cap * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 32 * 4 + 16;
 }
 
 __device__ __forceinline__ unsigned char *lds0() {
@@ -396,6 +397,7 @@ __device__ __forceinline__ u32 *sm_nmask(ExactSmem sm) { return (u32 *) (sm_emas
 __device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm.cap / 32 + 2); }
 __device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 2 * sm.rawwords); }
 __device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
+__device__ __forceinline__ u32 *sm_intent(ExactSmem sm) { return (u32 *) (sm_start(sm) + sm.cap); }
 
 __device__ __forceinline__ u64 spread32(u32 v) {
     u64 x = v;
@@ -987,6 +989,293 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B,
     }
 }
 
+// ------------------------------------------------------------------ long reads
+// slice t (1-based) of buffer_task_long, kmer.cpp:790-798: SLICE_LENGTH bases each, the
+// remainder len % SLICE_LENGTH goes to slice mid = (snum+1)/2
+__device__ __forceinline__ void long_slice(int t, int mid, int bonus, int SL, u32 &start, u32 &len) {
+    start = (u32) ((t - 1) * SL + (t > mid ? bonus : 0));
+    len = (u32) (SL + (t == mid ? bonus : 0));
+}
+
+// buffer_task_long, kmer.cpp:785-871.  The forward walk accumulates into temp_result_left,
+// whose destination (both, strand-canonical / forward) is only known when the walk ends, so
+// it runs twice: pass 1 decides, pass 2 re-decides the recorded slices and emits.  The
+// backward walk records straight into result.backward (kmer.cpp:840).
+template <int NW>
+__device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+    constexpr bool UB = NW > 0;
+    constexpr int NWB = NW > 0 ? NW : 1;
+    const ReadRef rd = get_read(B, it.unit);
+    const int SL = P.slice_len;
+    const int len = (int) rd.len;
+    const int snum = len / SL;
+    if (snum <= 0) return;  // read_fastq_long_thread drops reads shorter than SLICE_LENGTH (kmer.cpp:1184)
+    const int mid = (snum + 1) / 2, bonus = len % SL;
+    const u64 allk = all_k_mask(P.min_mer, P.max_mer);
+    auto slice_decide = [&](int t, u64 cand) {
+        u32 st, sl;
+        long_slice(t, mid, bonus, SL, st, sl);
+        load_segment(sm, rd, st, sl);
+        const double ub = UB ? lane_bounds<NWB>(rd, st, (int) sl, P.min_mer, P.max_mer) : 0.0;
+        return decide<UB>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, ub);
+    };
+    auto slice_len = [&](int t) { return (int) (SL + (t == mid ? bonus : 0)); };
+    // pass 1: forward chain (kmer.cpp:797-817)
+    int si[2] = {1, 1}, kmer[2] = {0, 0}, last_rec[2] = {0, 0};
+    bool rend[2] = {false, false};
+    for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {
+        const Decision d = slice_decide(ti, ti == 1 ? it.cand[0] : (ti == snum ? it.cand[1] : allk));
+        const int tk[2] = {d.kh, d.kl};
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            if (!rend[b]) last_rec[b] = ti;  // this slice was recorded into temp_result_left[b]
+            if (!rend[b] && tk[b] > 0 && (kmer[b] == tk[b] || ti == 1)) {
+                si[b] += 1;
+                kmer[b] = tk[b];
+            } else {
+                rend[b] = true;
+            }
+        }
+    }
+    // pass 2: emit temp_result_left: strand-canonical into both when every slice chained
+    // (kmer.cpp:819-830), else as is into forward (kmer.cpp:858-867)
+    {
+        const int upto = last_rec[0] > last_rec[1] ? last_rec[0] : last_rec[1];
+        const bool canon_h = si[0] == snum + 1, canon_l = si[1] == snum + 1;
+        const u32 th = canon_h ? TREW_TABLE_BOTH_HIGH : TREW_TABLE_FORWARD_HIGH;
+        const u32 tl = canon_l ? TREW_TABLE_BOTH_LOW : TREW_TABLE_FORWARD_LOW;
+        for (int ti = 1; ti <= upto; ti++) {
+            const Decision d = slice_decide(ti, ti == 1 ? it.cand[0] : (ti == snum ? it.cand[1] : allk));
+            const bool rh = ti <= last_rec[0] && d.kh > 0, rl = ti <= last_rec[1] && d.kl > 0;
+            if (rh && rl && d.kh == d.kl && canon_h == canon_l) {
+                record(sm, T, slice_len(ti), d.kh, (1u << th) | (1u << tl), canon_h);
+            } else {
+                if (rh) record(sm, T, slice_len(ti), d.kh, 1u << th, canon_h);
+                if (rl) record(sm, T, slice_len(ti), d.kl, 1u << tl, canon_l);
+            }
+        }
+    }
+    // backward chain (kmer.cpp:832-856)
+    if (si[0] <= snum || si[1] <= snum) {
+        int sj[2] = {snum, snum};
+        kmer[0] = kmer[1] = 0;
+        rend[0] = rend[1] = false;
+        for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
+            const Decision d = slice_decide(tj, tj == snum ? it.cand[1] : (tj == 1 ? it.cand[0] : allk));
+            const bool rh = !rend[0] && d.kh > 0, rl = !rend[1] && d.kl > 0;
+            if (rh && rl && d.kh == d.kl) {
+                record(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
+            } else {
+                if (rh) record(sm, T, slice_len(tj), d.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
+                if (rl) record(sm, T, slice_len(tj), d.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+            }
+            const int tk[2] = {d.kh, d.kl};
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                if (sj[b] >= si[b] && !rend[b] && tk[b] > 0 && (kmer[b] == tk[b] || tj == snum)) {
+                    sj[b] -= 1;
+                    kmer[b] = tk[b];
+                } else {
+                    rend[b] = true;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ paired reads
+// deferred emission: (slot, k, baseline) recorded into temp_result_left (temp 0) or _right (temp 1)
+__device__ __forceinline__ u32 pack_intent(int slot, int k, int b, int temp) {
+    return (u32) slot | ((u32) k << 3) | ((u32) b << 10) | ((u32) temp << 11) | (1u << 12);
+}
+
+// get_dir_seq, kmer.cpp:307-313
+__device__ __forceinline__ u64 dir_seq(int i, int k, u64 seq, bool is_for) {
+    if ((i <= 2) == is_for) return seq;
+    return min_rotation(revcomp(seq, k), k);
+}
+
+// buffer_task_pair, kmer.cpp:322-507, with the 128-bit twin's clear of temp_result_left after
+// the whole-read block (kmer.cpp:722-723; SURVEY G1 -- the one documented divergence from the
+// 64-bit branch, whose stale map makes results depend on thread scheduling).
+template <int NW>
+__device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+    constexpr bool UB = NW > 0;
+    constexpr int NWB = NW > 0 ? NW : 1;
+    const ReadRef r0 = stage_read(sm, get_read(B, 2ull * it.unit), 0);
+    const ReadRef r1 = stage_read(sm, get_read(B, 2ull * it.unit + 1), 1);
+    const int n1 = (int) r0.len, n2 = (int) r1.len;
+    const int n = n1 < n2 ? n1 : n2;
+    if (2 * P.min_mer > n) return;
+    u32 *intent = sm_intent(sm);
+    u32 n_int = 0;
+    const u32 lane = lane_id();
+    auto seg_of = [&](int slot) { return get_segment(TREW_MODE_PAIR, slot, (u32) n1, (u32) n2, P.min_mer, P.max_mer, P.slice_len); };
+    auto seg_decide = [&](int slot) {
+        const Segment sg = seg_of(slot);
+        const ReadRef &r = sg.mate ? r1 : r0;
+        load_segment(sm, r, sg.start, sg.len);
+        const double ub = UB ? lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer) : 0.0;
+        return decide<UB>(sm, P, (int) sg.len, sg.kmin, sg.kmax, it.cand[slot], ub);
+    };
+    auto add_intent = [&](int slot, int k, int b, int temp) {
+        if (k > 0 && n_int < 32) {
+            if (lane == 0) intent[n_int] = pack_intent(slot, k, b, temp);
+            n_int++;
+        }
+    };
+    // resolve the intent list: destination tables per (temp, baseline); plain[] rotation-canonical
+    // keys, canon[] strand-canonical keys.  Intents with equal (slot, k) share one evaluation.
+    auto flush = [&](const u32 (&plain)[2][2], const u32 (&canon)[2][2]) {
+        __syncthreads();
+        for (u32 i = 0; i < n_int; i++) {
+            const u32 e = rfl(intent[i]);
+            if (!(e >> 12)) continue;  // already merged into an earlier entry
+            const int slot = (int) (e & 7u), k = (int) ((e >> 3) & 127u);
+            u32 mp = 0, mc = 0;
+            for (u32 j = i; j < n_int; j++) {
+                const u32 f = rfl(intent[j]);
+                if ((f >> 12) && (int) (f & 7u) == slot && (int) ((f >> 3) & 127u) == k) {
+                    const int b = (int) ((f >> 10) & 1u), temp = (int) ((f >> 11) & 1u);
+                    mp |= plain[temp][b];
+                    mc |= canon[temp][b];
+                    if (j != i && lane == 0) intent[j] = 0;
+                }
+            }
+            __syncthreads();
+            if (mp | mc) {
+                const Segment sg = seg_of(slot);
+                load_segment(sm, sg.mate ? r1 : r0, sg.start, sg.len);
+                const KStat st = eval_k(sm, (int) sg.len, k, 0.0);
+                if (mp) emit_k(sm, T, st.n_items, k, mp, false);
+                if (mc) emit_k(sm, T, st.n_items, k, mc, true);
+            }
+        }
+        n_int = 0;
+        __syncthreads();
+    };
+    int lef_k[2] = {0, 0}, kmer[2] = {0, 0};
+    u64 kseq[2] = {0, 0};
+    if (4 * P.min_mer <= n) {
+        // fragment order R1-left, R1-right, R2-right, R2-left = slots 0..3 (kmer.cpp:338-340)
+        const int snum = 4;
+        int si[2] = {1, 1};
+        bool rend[2] = {false, false};
+        for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {  // kmer.cpp:347-374
+            const Decision d = seg_decide(ti - 1);
+            const int tk[2] = {d.kh, d.kl};
+            const u64 ts[2] = {d.sh, d.sl};
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                if (!rend[b]) add_intent(ti - 1, tk[b], b, ti <= 2 ? 0 : 1);
+                if (!rend[b] && tk[b] > 0 && ((kmer[b] == tk[b] && kseq[b] == dir_seq(ti, tk[b], ts[b], true)) || ti == 1)) {
+                    si[b] += 1;
+                    kmer[b] = tk[b];
+                    if (ti == 1) kseq[b] = ts[b];
+                } else {
+                    rend[b] = true;
+                }
+            }
+        }
+        lef_k[0] = kmer[0];
+        lef_k[1] = kmer[1];
+        // all four segments chained: both temps -> both, strand-canonical (kmer.cpp:378-399).
+        // The reference adds them BEFORE the backward chain refills the temps, so resolve now.
+        {
+            const u32 none[2][2] = {{0, 0}, {0, 0}};
+            u32 canon[2][2] = {{0, 0}, {0, 0}};
+            if (si[0] == snum + 1) canon[0][0] = canon[1][0] = 1u << TREW_TABLE_BOTH_HIGH;
+            if (si[1] == snum + 1) canon[0][1] = canon[1][1] = 1u << TREW_TABLE_BOTH_LOW;
+            // entries of a baseline that did not complete stay pending for the forward/backward flush
+            __syncthreads();
+            u32 keep = 0;
+            for (u32 i = 0; i < n_int; i++) {
+                const u32 e = rfl(intent[i]);
+                const int b = (int) ((e >> 10) & 1u);
+                if (si[b] != snum + 1) keep++;
+            }
+            if (keep == 0) {
+                flush(none, canon);
+            } else if (keep != n_int) {
+                // mixed: emit the completed baseline now, keep the other one in the list
+                u32 kept[32];
+                u32 nk = 0;
+                __syncthreads();
+                for (u32 i = 0; i < n_int; i++) {
+                    const u32 e = rfl(intent[i]);
+                    if (si[(e >> 10) & 1u] != snum + 1) kept[nk++] = e;
+                }
+                // drop kept ones from the list for this flush
+                for (u32 i = 0; i < n_int; i++) {
+                    const u32 e = rfl(intent[i]);
+                    if (si[(e >> 10) & 1u] != snum + 1 && lane == 0) intent[i] = 0;
+                }
+                flush(none, canon);
+                for (u32 i = 0; i < nk; i++)
+                    if (lane == 0) intent[i] = kept[i];
+                n_int = nk;
+                __syncthreads();
+            }
+        }
+        if (si[0] <= snum || si[1] <= snum) {  // backward chain, kmer.cpp:401-436
+            int sj[2] = {snum, snum};
+            kmer[0] = kmer[1] = 0;
+            rend[0] = rend[1] = false;
+            for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
+                const Decision d = seg_decide(tj - 1);
+                const int tk[2] = {d.kh, d.kl};
+                const u64 ts[2] = {d.sh, d.sl};
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    if (!rend[b]) add_intent(tj - 1, tk[b], b, tj <= 2 ? 1 : 0);
+                    if (sj[b] >= si[b] && !rend[b] && tk[b] > 0 &&
+                        ((kmer[b] == tk[b] && kseq[b] == dir_seq(tj, tk[b], ts[b], false)) || tj == snum)) {
+                        sj[b] -= 1;
+                        kmer[b] = tk[b];
+                        if (tj == snum) kseq[b] = ts[b];
+                    } else {
+                        rend[b] = true;
+                    }
+                }
+            }
+        }
+        {  // kmer.cpp:438-455: temp_left -> forward, temp_right -> backward for a baseline that did not complete
+            const u32 none[2][2] = {{0, 0}, {0, 0}};
+            u32 plain[2][2] = {{0, 0}, {0, 0}};
+            if (si[0] <= snum) {
+                plain[0][0] = 1u << TREW_TABLE_FORWARD_HIGH;
+                plain[1][0] = 1u << TREW_TABLE_BACKWARD_HIGH;
+            }
+            if (si[1] <= snum) {
+                plain[0][1] = 1u << TREW_TABLE_FORWARD_LOW;
+                plain[1][1] = 1u << TREW_TABLE_BACKWARD_LOW;
+            }
+            flush(plain, none);
+        }
+    }
+    if (4 * P.max_mer > n) {  // whole-read block, kmer.cpp:467-505
+        Decision lt = {0, 0, 0, 0}, rt = {0, 0, 0, 0};
+        if (lef_k[0] == 0 || lef_k[1] == 0) {
+            lt = seg_decide(4);
+            if (lef_k[0] == 0) add_intent(4, lt.kh, 0, 0);
+            if (lef_k[1] == 0) add_intent(4, lt.kl, 1, 0);
+        }
+        if (kmer[0] == 0 || kmer[1] == 0) {
+            rt = seg_decide(5);
+            if (kmer[0] == 0) add_intent(5, rt.kh, 0, 0);
+            if (kmer[1] == 0) add_intent(5, rt.kl, 1, 0);
+        }
+        u32 plain[2][2] = {{1u << TREW_TABLE_FORWARD_HIGH, 1u << TREW_TABLE_FORWARD_LOW}, {0, 0}};
+        u32 canon[2][2] = {{0, 0}, {0, 0}};
+        if (lef_k[0] == 0 && kmer[0] == 0 && lt.kh == rt.kh && lt.kh > 0 && lt.sh == min_rotation(revcomp(rt.sh, rt.kh), rt.kh))
+            canon[0][0] = 1u << TREW_TABLE_BOTH_HIGH;
+        if (lef_k[1] == 0 && kmer[1] == 0 && lt.kl == rt.kl && lt.kl > 0 && lt.sl == min_rotation(revcomp(rt.sl, rt.kl), rt.kl))
+            canon[0][1] = 1u << TREW_TABLE_BOTH_LOW;
+        flush(plain, canon);
+    }
+}
+
+
 // NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
 // NW == 0: long segments, pruning happens inside eval_k instead.
 template <int NW>
@@ -1009,6 +1298,10 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
             run_short<NW>(sm, P, B, T, it);
         else if (P.mode == TREW_MODE_SEGMENT)
             run_segment<NW>(sm, P, B, T, it, R);
+        else if (P.mode == TREW_MODE_LONG)
+            run_long<NW>(sm, P, B, T, it);
+        else
+            run_pair<NW>(sm, P, B, T, it);
         __syncthreads();
     }
 }
