@@ -146,6 +146,12 @@ uint64_t trew_pack_words(uint64_t n_bases);
 uint64_t trew_pack_reads(const char *buf, const int64_t *st, const int64_t *nd, uint64_t n_reads,
                          uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths);
 
+/* Same for mate pairs (PairQueueData, kmer.h:98-103): pair i is read i of each buffer; the
+ * output holds reads 2i (mate 1) and 2i+1 (mate 2), the layout TREW_MODE_PAIR expects. */
+uint64_t trew_pack_pairs(const char *buf1, const int64_t *st1, const int64_t *nd1,
+                         const char *buf2, const int64_t *st2, const int64_t *nd2, uint64_t n_pairs,
+                         uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths);
+
 /* ---- synthetic workloads of SURVEY.md section 8(d); identical on host and device ---- */
 /* short reads, TTAGGG-seeded: 1.0 % telomeric, 0.5 % junction, 1 % substitutions in those,
  * N with p = 5e-4.  Host: ASCII rows of read_len bytes + '\n'. */
@@ -164,6 +170,10 @@ int trew_hip_malloc(trew_hip_ctx *ctx, uint64_t bytes, void **d_ptr);
 int trew_hip_free(trew_hip_ctx *ctx, void *d_ptr);
 int trew_hip_memcpy_h2d(trew_hip_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int trew_hip_memcpy_d2h(trew_hip_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+/* pinned host memory for the double-buffered H2D copies of trew_hip_submit */
+int trew_hip_host_alloc(trew_hip_ctx *ctx, uint64_t bytes, void **h_ptr);
+int trew_hip_host_free(trew_hip_ctx *ctx, void *h_ptr);
+int trew_hip_device_count(void);
 int trew_hip_abi_version(void);
 
 #ifdef __cplusplus

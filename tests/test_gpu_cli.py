@@ -1,0 +1,122 @@
+"""End-to-end `trew` binary (FASTQ/.gz reader -> pack -> device scan -> CSV + Putative_TRM) against the oracle."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import oracle as O
+from oracle.output_oracle import add_totals
+from trew_amd import capi
+from conftest import GOLDEN, read_fastq
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TREW = os.path.join(ROOT, "trew_amd", "bin", "trew")
+
+
+def write_fastq(path, reads, crlf=False):
+    nl = b"\r\n" if crlf else b"\n"
+    data = b"".join(b"@r%d" % i + nl + r + nl + b"+" + nl + b"I" * len(r) + nl for i, r in enumerate(reads))
+    if path.endswith(".gz"):
+        with gzip.open(path, "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+def run(*args):
+    r = subprocess.run([TREW, *args], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    return r.stdout.splitlines()
+
+
+def expected(files_tables, min_mer):
+    lines, th, tl = [], {}, {}
+    for name, tables in files_tables:
+        h, lo = O.fold_tables(tables, min_mer)
+        lines += O.format_sections(os.path.realpath(name), h, lo)
+        add_totals(th, h)
+        add_totals(tl, lo)
+    return lines + O.putative_trm(th, tl)
+
+
+@pytest.mark.parametrize("name", ["test.fastq", "test.fastq.gz"])
+def test_cli_fixture_short(name):
+    path = os.path.join(GOLDEN, name)
+    out = run("short", "5", "32", path)
+    assert out == [">H:" + os.path.realpath(path), ">L:" + os.path.realpath(path), ">Putative_TRM", "NO_PUTATIVE_TRM,-1"]
+
+
+@pytest.mark.parametrize("name", ["test_long.fastq", "test_long.fastq.gz"])
+def test_cli_fixture_long(name):
+    path = os.path.join(GOLDEN, name)
+    out = run("long", "5", "32", path)
+    assert out == [">H:" + os.path.realpath(path), ">L:" + os.path.realpath(path), ">Putative_TRM", "NO_PUTATIVE_TRM,-1"]
+
+
+def test_cli_fixture_short_3_32():
+    # non-empty rows from the bundled fixture (k = 3 motifs), device limit MAX_MER <= 32
+    path = os.path.join(GOLDEN, "test.fastq")
+    reads = read_fastq(path)
+    p = O.OracleParams(min_mer=3, max_mer=32)
+    out = run("short", "3", "32", path, "-t", "3")
+    assert out == expected([(path, O.run_short(p, reads))], 3)
+    assert "3,TTA,157,105,0,-" in out
+
+
+def test_cli_short_synthetic_plain_gz_multi_file(tmp_path):
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 60000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    a = str(tmp_path / "a.fastq")
+    b = str(tmp_path / "b.fastq.gz")
+    write_fastq(a, reads[:40000])
+    write_fastq(b, reads[40000:])
+    p = O.OracleParams()
+    want = expected([(a, O.run_short(p, reads[:40000])), (b, O.run_short(p, reads[40000:]))], 5)
+    for threads in ("2", "5"):
+        assert run("short", "5", "32", a, b, "-t", threads) == want
+    assert any(line.startswith("6,TTAGGG,") for line in want)
+    assert want[-1] != "NO_PUTATIVE_TRM,-1"
+
+
+def test_cli_short_crlf_and_lowercase(tmp_path):
+    buf, st, nd = capi.synth_short_ascii(5, 0, 3000, 150)
+    reads = [buf[s:e + 1].lower() if i % 3 == 0 else buf[s:e + 1] for i, (s, e) in enumerate(zip(st, nd))]
+    a = str(tmp_path / "crlf.fastq")
+    write_fastq(a, reads, crlf=True)
+    # with CRLF the '\r' belongs to the sequence line (it is an invalid base), as in the reference reader
+    want = expected([(a, O.run_short(O.OracleParams(), [r + b"\r" for r in reads]))], 5)
+    assert run("short", "5", "32", a) == want
+
+
+def test_cli_pair(tmp_path):
+    b1, b2, st, nd = capi.synth_pair_ascii(20250218, 0, 30000, 150)
+    r1 = [b1[s:e + 1] for s, e in zip(st, nd)]
+    r2 = [b2[s:e + 1] for s, e in zip(st, nd)]
+    f1 = str(tmp_path / "r1.fastq.gz")
+    f2 = str(tmp_path / "r2.fastq")
+    write_fastq(f1, r1)
+    write_fastq(f2, r2)
+    want = expected([(f1, O.run_pair(O.OracleParams(), r1, r2))], 5)
+    assert run("short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2, "-t", "4") == want
+
+
+def test_cli_long(tmp_path):
+    from test_gpu_parity import _long_reads
+
+    reads = _long_reads(77, 300)
+    a = str(tmp_path / "long.fastq")
+    write_fastq(a, reads)
+    want = expected([(a, O.run_long(O.OracleParams(), reads))], 5)
+    assert run("long", "5", "32", a, "-t", "3") == want
+    assert len(want) > 6
+
+
+def test_cli_rejects_long_read_in_short_mode(tmp_path):
+    a = str(tmp_path / "x.fastq")
+    write_fastq(a, [b"ACGT" * 300])
+    r = subprocess.run([TREW, "short", "5", "32", a], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert "This mode is designed for short-read sequencing. Please use 'trew long'." in r.stderr

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "trew_hip_filter_masks", "trew_hip_last_timing", "trew_pack_words", "trew_pack_reads",
     "trew_synth_short_ascii", "trew_synth_short_device", "trew_synth_pair_ascii", "trew_synth_pair_device",
     "trew_hip_malloc", "trew_hip_free", "trew_hip_memcpy_h2d", "trew_hip_memcpy_d2h", "trew_hip_abi_version",
+    "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
 )
 
 

@@ -64,6 +64,32 @@ static int fail(trew_hip_ctx *ctx, const std::string &msg) {
 
 extern "C" int trew_hip_abi_version(void) { return TREW_HIP_ABI_VERSION; }
 
+extern "C" int trew_hip_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+extern "C" int trew_hip_host_alloc(trew_hip_ctx *ctx, uint64_t bytes, void **h_ptr) {
+    if (!ctx || !h_ptr) return -1;
+    hipError_t e = hipSetDevice(ctx->p.device);
+    if (e == hipSuccess) e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        return (int) e;
+    }
+    return 0;
+}
+
+extern "C" int trew_hip_host_free(trew_hip_ctx *ctx, void *h_ptr) {
+    if (!ctx) return -1;
+    hipError_t e = hipHostFree(h_ptr);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipHostFree: ") + hipGetErrorString(e);
+        return (int) e;
+    }
+    return 0;
+}
+
 extern "C" const char *trew_hip_last_error(const trew_hip_ctx *ctx) {
     return ctx ? ctx->err.c_str() : g_init_error.c_str();
 }
@@ -427,42 +453,68 @@ extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filte
 // ---------------------------------------------------------------- host packing
 extern "C" uint64_t trew_pack_words(uint64_t n_bases) { return 3ull * ((n_bases + 31ull) / 32ull); }
 
+namespace {
+struct PackLut {
+    unsigned char v[256];
+    PackLut() {
+        // codes[], kmer.cpp:14-31: T=0 G=1 C=2 A=3, either case; everything else is "N"
+        for (int i = 0; i < 256; i++) v[i] = 4;
+        v[(int) 'T'] = v[(int) 't'] = 0;
+        v[(int) 'G'] = v[(int) 'g'] = 1;
+        v[(int) 'C'] = v[(int) 'c'] = 2;
+        v[(int) 'A'] = v[(int) 'a'] = 3;
+    }
+};
+const PackLut g_lut;
+
+// one read -> triples; returns words written
+inline uint64_t pack_one(const unsigned char *p, uint64_t len, uint32_t *out) {
+    const uint64_t nw = (len + 31) / 32;
+    for (uint64_t j = 0; j < nw; j++) {
+        uint32_t lo = 0, hi = 0, nm = 0;
+        const uint64_t m = std::min<uint64_t>(32, len - 32 * j);
+        const unsigned char *q = p + 32 * j;
+        for (uint64_t i = 0; i < m; i++) {
+            const unsigned c = g_lut.v[q[i]];
+            lo |= (uint32_t) (c & 1u) << i;
+            hi |= (uint32_t) ((c >> 1) & 1u) << i;
+            nm |= (uint32_t) (c >> 2) << i;
+        }
+        out[3 * j + 0] = lo & ~nm;
+        out[3 * j + 1] = hi & ~nm;
+        out[3 * j + 2] = nm;
+    }
+    return 3 * nw;
+}
+}  // namespace
+
 extern "C" uint64_t trew_pack_reads(const char *buf, const int64_t *st, const int64_t *nd, uint64_t n_reads,
                                     uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths) {
-    // codes[], kmer.cpp:14-31: T=0 G=1 C=2 A=3, either case; everything else is "N"
-    static unsigned char lut[256];
-    static bool init = false;
-    if (!init) {
-        for (int i = 0; i < 256; i++) lut[i] = 4;
-        lut[(int) 'T'] = lut[(int) 't'] = 0;
-        lut[(int) 'G'] = lut[(int) 'g'] = 1;
-        lut[(int) 'C'] = lut[(int) 'c'] = 2;
-        lut[(int) 'A'] = lut[(int) 'a'] = 3;
-        init = true;
-    }
     uint64_t w = 0;
     for (uint64_t r = 0; r < n_reads; r++) {
         const int64_t n = nd[r] - st[r] + 1;
         const uint64_t len = n > 0 ? (uint64_t) n : 0;
-        const uint64_t nw = (len + 31) / 32;
-        if (w + 3 * nw > words_cap || w > 0xffffffffull) return (uint64_t) -1;
+        if (w + 3 * ((len + 31) / 32) > words_cap || w > 0xffffffffull) return (uint64_t) -1;
         offsets[r] = (uint32_t) w;
         lengths[r] = (uint32_t) len;
-        const unsigned char *p = (const unsigned char *) buf + st[r];
-        for (uint64_t j = 0; j < nw; j++) {
-            uint32_t lo = 0, hi = 0, nm = 0;
-            const uint64_t m = std::min<uint64_t>(32, len - 32 * j);
-            for (uint64_t i = 0; i < m; i++) {
-                const unsigned c = lut[p[32 * j + i]];
-                lo |= (uint32_t) (c & 1u) << i;
-                hi |= (uint32_t) ((c >> 1) & 1u) << i;
-                nm |= (uint32_t) (c >> 2) << i;
-            }
-            lo &= ~nm;
-            hi &= ~nm;
-            words[w++] = lo;
-            words[w++] = hi;
-            words[w++] = nm;
+        w += pack_one((const unsigned char *) buf + st[r], len, words + w);
+    }
+    return w;
+}
+
+extern "C" uint64_t trew_pack_pairs(const char *buf1, const int64_t *st1, const int64_t *nd1,
+                                    const char *buf2, const int64_t *st2, const int64_t *nd2, uint64_t n_pairs,
+                                    uint32_t *words, uint64_t words_cap, uint32_t *offsets, uint32_t *lengths) {
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < n_pairs; r++) {
+        for (int mate = 0; mate < 2; mate++) {
+            const char *buf = mate ? buf2 : buf1;
+            const int64_t s = mate ? st2[r] : st1[r], e = mate ? nd2[r] : nd1[r];
+            const uint64_t len = e - s + 1 > 0 ? (uint64_t) (e - s + 1) : 0;
+            if (w + 3 * ((len + 31) / 32) > words_cap || w > 0xffffffffull) return (uint64_t) -1;
+            offsets[2 * r + mate] = (uint32_t) w;
+            lengths[2 * r + mate] = (uint32_t) len;
+            w += pack_one((const unsigned char *) buf + s, len, words + w);
         }
     }
     return w;
