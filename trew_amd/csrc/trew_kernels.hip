@@ -1089,6 +1089,9 @@ __device__ __forceinline__ u32 pack_intent(int slot, int k, int b, int temp) {
     return (u32) slot | ((u32) k << 3) | ((u32) b << 10) | ((u32) temp << 11) | (1u << 12);
 }
 
+// destination byte of flush(): temp (0 left, 1 right), baseline (0 high, 1 low) -> table
+__device__ __forceinline__ u32 dest(int temp, int b, int table) { return (1u << table) << (8 * (2 * temp + b)); }
+
 // get_dir_seq, kmer.cpp:307-313
 __device__ __forceinline__ u64 dir_seq(int i, int k, u64 seq, bool is_for) {
     if ((i <= 2) == is_for) return seq;
@@ -1099,11 +1102,12 @@ __device__ __forceinline__ u64 dir_seq(int i, int k, u64 seq, bool is_for) {
 // the whole-read block (kmer.cpp:722-723; SURVEY G1 -- the one documented divergence from the
 // 64-bit branch, whose stale map makes results depend on thread scheduling).
 template <int NW>
-__device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+__device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem *itp) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef r0 = stage_read(sm, get_read(B, 2ull * it.unit), 0);
-    const ReadRef r1 = stage_read(sm, get_read(B, 2ull * it.unit + 1), 1);
+    const u64 unit = itp->unit;
+    const ReadRef r0 = stage_read(sm, get_read(B, 2ull * unit), 0);
+    const ReadRef r1 = stage_read(sm, get_read(B, 2ull * unit + 1), 1);
     const int n1 = (int) r0.len, n2 = (int) r1.len;
     const int n = n1 < n2 ? n1 : n2;
     if (2 * P.min_mer > n) return;
@@ -1116,7 +1120,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const ReadRef &r = sg.mate ? r1 : r0;
         load_segment(sm, r, sg.start, sg.len);
         const double ub = UB ? lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer) : 0.0;
-        return decide<UB>(sm, P, (int) sg.len, sg.kmin, sg.kmax, it.cand[slot], ub);
+        return decide<UB>(sm, P, (int) sg.len, sg.kmin, sg.kmax, itp->cand[slot], ub);  // global load: slot is dynamic
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
         if (k > 0 && n_int < 32) {
@@ -1125,21 +1129,24 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
     };
     // resolve the intent list: destination tables per (temp, baseline); plain[] rotation-canonical
-    // keys, canon[] strand-canonical keys.  Intents with equal (slot, k) share one evaluation.
-    auto flush = [&](const u32 (&plain)[2][2], const u32 (&canon)[2][2]) {
+    // keys, canon[] strand-canonical keys.  Only entries whose baseline is in bmask are consumed;
+    // intents with equal (slot, k) share one evaluation.
+    // plain/canon: byte (2*temp + baseline) = table mask (packed so nothing is indexed in scratch)
+    auto flush = [&](u32 plain, u32 canon, u32 bmask, bool clear) {
         __syncthreads();
         for (u32 i = 0; i < n_int; i++) {
             const u32 e = rfl(intent[i]);
-            if (!(e >> 12)) continue;  // already merged into an earlier entry
+            if (!(e >> 12) || !((bmask >> ((e >> 10) & 1u)) & 1u)) continue;  // consumed earlier / other baseline
             const int slot = (int) (e & 7u), k = (int) ((e >> 3) & 127u);
             u32 mp = 0, mc = 0;
             for (u32 j = i; j < n_int; j++) {
                 const u32 f = rfl(intent[j]);
-                if ((f >> 12) && (int) (f & 7u) == slot && (int) ((f >> 3) & 127u) == k) {
-                    const int b = (int) ((f >> 10) & 1u), temp = (int) ((f >> 11) & 1u);
-                    mp |= plain[temp][b];
-                    mc |= canon[temp][b];
-                    if (j != i && lane == 0) intent[j] = 0;
+                const u32 fb = (f >> 10) & 1u;
+                if ((f >> 12) && ((bmask >> fb) & 1u) && (int) (f & 7u) == slot && (int) ((f >> 3) & 127u) == k) {
+                    const u32 temp = (f >> 11) & 1u;
+                    mp |= (plain >> (8u * (2u * temp + fb))) & 0xffu;
+                    mc |= (canon >> (8u * (2u * temp + fb))) & 0xffu;
+                    if (lane == 0) intent[j] = 0;
                 }
             }
             __syncthreads();
@@ -1151,7 +1158,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                 if (mc) emit_k(sm, T, st.n_items, k, mc, true);
             }
         }
-        n_int = 0;
+        if (clear) n_int = 0;
         __syncthreads();
     };
     int lef_k[2] = {0, 0}, kmer[2] = {0, 0};
@@ -1180,42 +1187,19 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         lef_k[0] = kmer[0];
         lef_k[1] = kmer[1];
         // all four segments chained: both temps -> both, strand-canonical (kmer.cpp:378-399).
-        // The reference adds them BEFORE the backward chain refills the temps, so resolve now.
+        // The reference adds them BEFORE the backward chain refills the temps, so resolve that
+        // baseline now; the other baseline's entries stay pending.
         {
-            const u32 none[2][2] = {{0, 0}, {0, 0}};
-            u32 canon[2][2] = {{0, 0}, {0, 0}};
-            if (si[0] == snum + 1) canon[0][0] = canon[1][0] = 1u << TREW_TABLE_BOTH_HIGH;
-            if (si[1] == snum + 1) canon[0][1] = canon[1][1] = 1u << TREW_TABLE_BOTH_LOW;
-            // entries of a baseline that did not complete stay pending for the forward/backward flush
-            __syncthreads();
-            u32 keep = 0;
-            for (u32 i = 0; i < n_int; i++) {
-                const u32 e = rfl(intent[i]);
-                const int b = (int) ((e >> 10) & 1u);
-                if (si[b] != snum + 1) keep++;
+            u32 canon = 0, bmask = 0;
+            if (si[0] == snum + 1) {
+                canon |= dest(0, 0, TREW_TABLE_BOTH_HIGH) | dest(1, 0, TREW_TABLE_BOTH_HIGH);
+                bmask |= 1u;
             }
-            if (keep == 0) {
-                flush(none, canon);
-            } else if (keep != n_int) {
-                // mixed: emit the completed baseline now, keep the other one in the list
-                u32 kept[32];
-                u32 nk = 0;
-                __syncthreads();
-                for (u32 i = 0; i < n_int; i++) {
-                    const u32 e = rfl(intent[i]);
-                    if (si[(e >> 10) & 1u] != snum + 1) kept[nk++] = e;
-                }
-                // drop kept ones from the list for this flush
-                for (u32 i = 0; i < n_int; i++) {
-                    const u32 e = rfl(intent[i]);
-                    if (si[(e >> 10) & 1u] != snum + 1 && lane == 0) intent[i] = 0;
-                }
-                flush(none, canon);
-                for (u32 i = 0; i < nk; i++)
-                    if (lane == 0) intent[i] = kept[i];
-                n_int = nk;
-                __syncthreads();
+            if (si[1] == snum + 1) {
+                canon |= dest(0, 1, TREW_TABLE_BOTH_LOW) | dest(1, 1, TREW_TABLE_BOTH_LOW);
+                bmask |= 2u;
             }
+            if (bmask) flush(0u, canon, bmask, false);
         }
         if (si[0] <= snum || si[1] <= snum) {  // backward chain, kmer.cpp:401-436
             int sj[2] = {snum, snum};
@@ -1240,17 +1224,10 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             }
         }
         {  // kmer.cpp:438-455: temp_left -> forward, temp_right -> backward for a baseline that did not complete
-            const u32 none[2][2] = {{0, 0}, {0, 0}};
-            u32 plain[2][2] = {{0, 0}, {0, 0}};
-            if (si[0] <= snum) {
-                plain[0][0] = 1u << TREW_TABLE_FORWARD_HIGH;
-                plain[1][0] = 1u << TREW_TABLE_BACKWARD_HIGH;
-            }
-            if (si[1] <= snum) {
-                plain[0][1] = 1u << TREW_TABLE_FORWARD_LOW;
-                plain[1][1] = 1u << TREW_TABLE_BACKWARD_LOW;
-            }
-            flush(plain, none);
+            u32 plain = 0;
+            if (si[0] <= snum) plain |= dest(0, 0, TREW_TABLE_FORWARD_HIGH) | dest(1, 0, TREW_TABLE_BACKWARD_HIGH);
+            if (si[1] <= snum) plain |= dest(0, 1, TREW_TABLE_FORWARD_LOW) | dest(1, 1, TREW_TABLE_BACKWARD_LOW);
+            flush(plain, 0u, 3u, true);
         }
     }
     if (4 * P.max_mer > n) {  // whole-read block, kmer.cpp:467-505
@@ -1265,20 +1242,20 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             if (kmer[0] == 0) add_intent(5, rt.kh, 0, 0);
             if (kmer[1] == 0) add_intent(5, rt.kl, 1, 0);
         }
-        u32 plain[2][2] = {{1u << TREW_TABLE_FORWARD_HIGH, 1u << TREW_TABLE_FORWARD_LOW}, {0, 0}};
-        u32 canon[2][2] = {{0, 0}, {0, 0}};
+        const u32 plain = dest(0, 0, TREW_TABLE_FORWARD_HIGH) | dest(0, 1, TREW_TABLE_FORWARD_LOW);
+        u32 canon = 0;
         if (lef_k[0] == 0 && kmer[0] == 0 && lt.kh == rt.kh && lt.kh > 0 && lt.sh == min_rotation(revcomp(rt.sh, rt.kh), rt.kh))
-            canon[0][0] = 1u << TREW_TABLE_BOTH_HIGH;
+            canon |= dest(0, 0, TREW_TABLE_BOTH_HIGH);
         if (lef_k[1] == 0 && kmer[1] == 0 && lt.kl == rt.kl && lt.kl > 0 && lt.sl == min_rotation(revcomp(rt.sl, rt.kl), rt.kl))
-            canon[0][1] = 1u << TREW_TABLE_BOTH_LOW;
-        flush(plain, canon);
+            canon |= dest(0, 1, TREW_TABLE_BOTH_LOW);
+        flush(plain, canon, 3u, true);
     }
 }
 
 
 // NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
 // NW == 0: long segments, pruning happens inside eval_k instead.
-template <int NW>
+template <int NW, int MODE>
 __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
                                                    u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
     ExactSmem sm;
@@ -1294,14 +1271,15 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         w = rfl(w);
         if (w >= n) break;
         const WorkItem it = wl[w];
-        if (P.mode == TREW_MODE_SHORT)
+        // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
+        if (MODE == TREW_MODE_SHORT)
             run_short<NW>(sm, P, B, T, it);
-        else if (P.mode == TREW_MODE_SEGMENT)
+        else if (MODE == TREW_MODE_SEGMENT)
             run_segment<NW>(sm, P, B, T, it, R);
-        else if (P.mode == TREW_MODE_LONG)
+        else if (MODE == TREW_MODE_LONG)
             run_long<NW>(sm, P, B, T, it);
         else
-            run_pair<NW>(sm, P, B, T, it);
+            run_pair<NW>(sm, P, B, T, &wl[w]);
         __syncthreads();
     }
 }
@@ -1421,18 +1399,27 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
     const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
+    typedef void (*kern_t)(DevParams, DevBatch, DevTable, const WorkItem *, u32 *, u32, SegResults, u32, u32);
+    kern_t fn = nullptr;
+#define TREW_PICK_MODE(NWV)                                                           \
+    switch (P.mode) {                                                                 \
+    case TREW_MODE_SHORT: fn = exact_kernel<NWV, TREW_MODE_SHORT>; break;             \
+    case TREW_MODE_PAIR: fn = exact_kernel<NWV, TREW_MODE_PAIR>; break;               \
+    case TREW_MODE_LONG: fn = exact_kernel<NWV, TREW_MODE_LONG>; break;               \
+    default: fn = exact_kernel<NWV, TREW_MODE_SEGMENT>; break;                        \
+    }
+    switch (nw) {
+    case 3: TREW_PICK_MODE(3) break;
+    case 5: TREW_PICK_MODE(5) break;
+    case 10: TREW_PICK_MODE(10) break;
+    default: TREW_PICK_MODE(0) break;
+    }
+#undef TREW_PICK_MODE
     int per_cu = 8;
-    const void *fn = nw == 3 ? (const void *) exact_kernel<3> : nw == 5 ? (const void *) exact_kernel<5>
-                   : nw == 10 ? (const void *) exact_kernel<10> : (const void *) exact_kernel<0>;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fn, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
     per_cu = per_cu > 32 ? 32 : per_cu;
     const u32 grid = (u32) std::min<u64>((u64) n_cu * (u64) per_cu, std::max<u64>(n_units, 1));
-    switch (nw) {
-    case 3: hipLaunchKernelGGL(exact_kernel<3>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
-    case 5: hipLaunchKernelGGL(exact_kernel<5>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
-    case 10: hipLaunchKernelGGL(exact_kernel<10>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
-    default: hipLaunchKernelGGL(exact_kernel<0>, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords); break;
-    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords);
     return hipGetLastError();
 }
 
