@@ -115,6 +115,13 @@ __device__ __forceinline__ void prefix_parity(const u32 (&f)[NW], u32 (&P)[NW]) 
     }
 }
 
+__device__ __forceinline__ u64 all_k_mask(int kmin, int kmax) {
+    if (kmax < kmin) return 0;
+    u64 hi = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
+    u64 lo = (1ull << (kmin - 1)) - 1ull;
+    return hi & ~lo;
+}
+
 // word j of (x >> k), k = 32*WS + bs, zero-extended above word NW-1
 template <int NW, int WS>
 __device__ __forceinline__ u32 shr_word(const u32 (&x)[NW], int j, u32 bs) {
@@ -124,67 +131,91 @@ __device__ __forceinline__ u32 shr_word(const u32 (&x)[NW], int j, u32 bs) {
 }
 
 // One k of the prefilter.  V holds V_k (windows with no N) on entry and V_{k+1} on exit.
+// NWW = number of mask words that can still hold a window at this k (compile-time, so the
+// per-word work has no scalar branches).
 // Stage 1 uses two parities (4 buckets); the third parity (8 buckets) is evaluated only
 // when some lane of the wave would otherwise get its FIRST candidate from the 4-bucket
 // bound.  Lanes that already own a candidate keep the looser -- still sound -- verdict:
-// the exact kernel prunes their extra candidates itself (eval_k's `need`).  The result of
+// the exact kernel prunes their extra candidates itself (lane_bounds).  The result of
 // a lane never depends on its neighbours: 8-bucket max <= 4-bucket max.
-template <int NW, int WS>
+// Measured on MI355X (tools/valu_rate.hip): v_alignbit / v_bcnt / v_bitop3 issue at ~4.3
+// cycles per wave-instruction, VOP2 logic at ~1.5; the slow ones are what is minimised here
+// (e.g. bucket 00 is COUNT minus the other three instead of a fourth popcount).
+template <int NW, int WS, int NWW>
 __device__ __forceinline__ void filter_k(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW],
-                                         const u32 (&v1)[NW], u32 (&V)[NW], int k, int nww, int kmin, int kmax,
-                                         float lowf, u64 &cand) {
+                                         const u32 (&v1)[NW], u32 (&V)[NW], int k, float lowf, u32 &cand_lo, u32 &cand_hi) {
     const u32 bs = (u32) k & 31u;
-    u32 c00 = 0, c01 = 0, c10 = 0, c11 = 0, count = 0;
+    u32 c01 = 0, c10 = 0, c11 = 0, count = 0;
 #pragma unroll
-    for (int j = 0; j < NW; j++) {
-        if (j < nww) {  // wave-uniform: words that can still hold a window
+    for (int j = 0; j < NWW; j++) {
+        const u32 F1 = P1[j] ^ shr_word<NW, WS>(P1, j, bs), F2 = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
+        const u32 v = V[j];
+        const u32 a1 = v & F1;
+        const u32 a11 = a1 & F2;
+        count += __popc(v);
+        c11 += __popc(a11);
+        c10 += __popc(a1 ^ a11);
+        c01 += __popc((v ^ a1) & F2);
+    }
+    const u32 c00 = count - c01 - c10 - c11;
+    const u32 m4 = max(max(c00, c01), max(c10, c11));
+    // MAX <= m4; MAX/COUNT >= LOW needs m4 >= LOW*COUNT > lowf*COUNT (lowf < LOW*(1-1e-6), COUNT > 0);
+    // the strict '>' also rejects COUNT == 0 (m4 == 0)
+    const float thr = (float) count * lowf;
+    const bool pass4 = (float) m4 > thr;
+    bool pass = pass4;
+    const bool first = (cand_lo | cand_hi) == 0;
+    if (__any(pass4 && first)) {
+        u32 c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0;
+#pragma unroll
+        for (int j = 0; j < NWW; j++) {
             const u32 F1 = P1[j] ^ shr_word<NW, WS>(P1, j, bs), F2 = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
+            const u32 F3 = P3[j] ^ shr_word<NW, WS>(P3, j, bs);
             const u32 v = V[j];
             const u32 a1 = v & F1, a0 = v ^ a1;
-            const u32 a11 = a1 & F2, a01 = a0 & F2;
-            count += __popc(v);
-            c11 += __popc(a11);
-            c10 += __popc(a1 ^ a11);
-            c01 += __popc(a01);
-            c00 += __popc(a0 ^ a01);
+            const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
+            const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
+            c111 += __popc(b111);
+            c110 += __popc(a11 ^ b111);
+            c101 += __popc(b101);
+            c100 += __popc(a10 ^ b101);
+            c011 += __popc(b011);
+            c010 += __popc(a01 ^ b011);
+            c001 += __popc(b001);
         }
-    }
-    const u32 m4 = max(max(c00, c01), max(c10, c11));
-    const bool inrange = count != 0u && k >= kmin && k <= kmax;
-    const float thr = (float) count * lowf;  // lowf < LOW*(1-1e-6): float rounding can only keep more
-    const bool pass4 = inrange && (float) m4 >= thr;
-    bool pass = pass4;
-    if (__any(pass4 && cand == 0)) {
-        u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0;
-#pragma unroll
-        for (int j = 0; j < NW; j++) {
-            if (j < nww) {
-                const u32 F1 = P1[j] ^ shr_word<NW, WS>(P1, j, bs), F2 = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
-                const u32 F3 = P3[j] ^ shr_word<NW, WS>(P3, j, bs);
-                const u32 v = V[j];
-                const u32 a1 = v & F1, a0 = v ^ a1;
-                const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
-                const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
-                c111 += __popc(b111);
-                c110 += __popc(a11 ^ b111);
-                c101 += __popc(b101);
-                c100 += __popc(a10 ^ b101);
-                c011 += __popc(b011);
-                c010 += __popc(a01 ^ b011);
-                c001 += __popc(b001);
-                c000 += __popc(a00 ^ b001);
-            }
-        }
+        const u32 c000 = count - c001 - c010 - c011 - c100 - c101 - c110 - c111;
         const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
-        const bool pass8 = inrange && (float) m8 >= thr;
-        pass = cand == 0 ? pass8 : pass4;
+        pass = first ? ((float) m8 > thr) : pass4;
     }
-    cand |= pass ? (1ull << (k - 1)) : 0ull;
+    if (k <= 32)
+        cand_lo |= pass ? (1u << ((k - 1) & 31)) : 0u;
+    else
+        cand_hi |= pass ? (1u << ((k - 33) & 31)) : 0u;
     // V_{k+1} = V_k & (v1 >> k)
 #pragma unroll
-    for (int j = 0; j < NW; j++)
-        if (j < nww) V[j] &= shr_word<NW, WS>(v1, j, bs);
+    for (int j = 0; j < NWW; j++) V[j] &= shr_word<NW, WS>(v1, j, bs);
 }
+
+// k range [klo, khi] split by the number of window words: windows i <= max_seg - k need
+// ceil((max_seg - k + 1) / 32) words.  Recursion over NWW keeps every trip count static.
+template <int NW, int WS, int NWW>
+struct FilterRange {
+    static __device__ __forceinline__ void run(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], const u32 (&v1)[NW],
+                                               u32 (&V)[NW], int klo, int khi, int max_seg, float lowf, u32 &clo, u32 &chi) {
+        // k values whose windows need exactly NWW words (or more than NW: clamp) : max_seg+1-32*NWW < k <= max_seg+1-32*(NWW-1)
+        int a = max_seg + 2 - 32 * NWW, b = max_seg + 1 - 32 * (NWW - 1);
+        if (NWW == NW) a = klo;  // segments are never longer than the instantiation allows
+        a = a < klo ? klo : a;
+        b = b > khi ? khi : b;
+        for (int k = a; k <= b; k++) filter_k<NW, WS, NWW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
+        FilterRange<NW, WS, NWW - 1>::run(P1, P2, P3, v1, V, klo, khi, max_seg, lowf, clo, chi);
+    }
+};
+template <int NW, int WS>
+struct FilterRange<NW, WS, 0> {
+    static __device__ __forceinline__ void run(const u32 (&)[NW], const u32 (&)[NW], const u32 (&)[NW], const u32 (&)[NW], u32 (&)[NW],
+                                               int, int, int, float, u32 &, u32 &) {}
+};
 
 // Candidate-k mask of one segment (bit k-1).  lo/hi/nm hold the segment's
 // planes from bit 0; L <= 32*NW-1 bases.  gmin..gmax is the wave-uniform k
@@ -225,27 +256,20 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 #pragma unroll
         for (int j = 0; j < NW; j++) V[j] &= shr_word<NW, 1>(v1, j, (u32) t & 31u);
     }
-    u64 cand = 0;
+    u32 clo = 0, chi = 0;
     const int g31 = gmax < 31 ? gmax : 31;
-    for (int k = gmin; k <= g31; k++) {
-        int nww = (max_seg - k + 1 + 31) >> 5;
-        nww = nww < 0 ? 0 : nww;
-        filter_k<NW, 0>(P1, P2, P3, v1, V, k, nww, kmin, kmax, lowf, cand);
+    if (NW <= 5) {
+        FilterRange<NW, 0, NW>::run(P1, P2, P3, v1, V, gmin, g31, max_seg, lowf, clo, chi);
+        FilterRange<NW, 1, NW>::run(P1, P2, P3, v1, V, gmin > 32 ? gmin : 32, gmax, max_seg, lowf, clo, chi);
+    } else {
+        // long segments: all words every k (static trip counts would multiply the code size)
+        for (int k = gmin; k <= g31; k++) filter_k<NW, 0, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
+        for (int k = gmin > 32 ? gmin : 32; k <= gmax; k++) filter_k<NW, 1, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
     }
-    for (int k = gmin > 32 ? gmin : 32; k <= gmax; k++) {
-        int nww = (max_seg - k + 1 + 31) >> 5;
-        nww = nww < 0 ? 0 : nww;
-        filter_k<NW, 1>(P1, P2, P3, v1, V, k, nww, kmin, kmax, lowf, cand);
-    }
-    return cand;
+    // only k inside the segment's own range can be candidates
+    return ((((u64) chi) << 32) | clo) & all_k_mask(kmin, kmax);
 }
 
-__device__ __forceinline__ u64 all_k_mask(int kmin, int kmax) {
-    if (kmax < kmin) return 0;
-    u64 hi = kmax >= 64 ? ~0ull : ((1ull << kmax) - 1ull);
-    u64 lo = (1ull << (kmin - 1)) - 1ull;
-    return hi & ~lo;
-}
 
 template <int NW>
 __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, WorkItem *wl, u32 *wl_count, u32 wl_cap,
