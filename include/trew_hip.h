@@ -52,7 +52,8 @@ enum {
 /* debug / test flags for trew_hip_params.flags */
 enum {
     TREW_FLAG_NO_FILTER = 1, /* skip the bucket-bound prefilter: every k is a candidate (exact path only) */
-    TREW_FLAG_DEBUG_NO_EMIT = 2 /* timing experiments only: drop every table update (results are empty) */
+    TREW_FLAG_DEBUG_NO_EMIT = 2, /* timing experiments only: drop every table update (results are empty) */
+    TREW_FLAG_DEBUG_NO_KLOOP = 4 /* timing experiments only: prefilter without its k loop (nothing is flagged) */
 };
 
 /* Replaces the eight configuration globals MIN_MER ... HIGH_BASELINE

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, Wo
                 if (P.flags & TREW_FLAG_NO_FILTER)
                     m = all_k_mask(sg.kmin, sg.kmax);
                 else
-                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer, P.max_mer, max_seg, P.lowf);
+                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer,
+                                           (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer, max_seg, P.lowf);
                 masks[slot] = ok ? m : 0ull;
             }
             // a segment too long for this instantiation must never be dropped silently
