@@ -587,6 +587,8 @@ __attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, in
     st.n_items = (u32) W;
 }
 
+__device__ void eval_runs(ExactSmem sm, int W, int k, KStat &st);
+
 // One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
 // 1936-1967) on the segment staged in sm.  Lemma A: two
 // adjacent valid windows i, i+1 are in the same rotation class iff base i ==
@@ -662,6 +664,14 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
             return st;
         }
     }
+    eval_runs(sm, W, k, st);
+    return st;
+}
+
+// Second half of eval_k: vmask[] / emask[] (+ one zero word) are in LDS, visible to the wave.
+__attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, KStat &st) {
+    const u32 lane = lane_id();
+    const int rounds = (W + 63) >> 6;
     // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
     u32 R = 0, count = 0;
     u64 carry = 0;
@@ -679,7 +689,7 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
     if (R > 64) {
         eval_k_windows(sm, W, k, st);
         __syncthreads();
-        return st;
+        return;
     }
     // one lane per run
     u64 canon = ~0ull;
@@ -725,7 +735,6 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
     wave_best(key, canon, st);
     st.n_items = R;
     __syncthreads();
-    return st;
 }
 
 // add every class of the k just evaluated to the tables in table_mask (bit t).
@@ -759,8 +768,16 @@ __device__ __forceinline__ u32 shr_var_word(const u32 (&x)[NW], int j, u32 off) 
 // (filter_segment), the shift amounts simply differ per lane.  Used by decide()
 // to discard a candidate k with one readlane instead of a pass over its windows.
 // Returns (double) maxbucket / (double) count, 0 where there is no valid window.
+// what lane l knows about k = gmin + l of one segment
 template <int NW>
-__attribute__((noinline)) __device__ double lane_bounds(const ReadRef &rd, u32 s, int L, int gmin, int gmax) {
+struct LaneMasks {
+    u32 V[NW];  // bit i: window i has no N and fits the segment
+    u32 E[NW];  // bit i: base i == base i+k (meaningful where windows i and i+1 are both valid)
+    double ub;  // maxbucket / COUNT, an upper bound of MAX / COUNT (0 where COUNT == 0)
+};
+
+template <int NW>
+__device__ __forceinline__ void lane_bounds(const ReadRef &rd, u32 s, int L, int gmin, int gmax, LaneMasks<NW> &out) {
     u32 lo[NW], hi[NW], nm[NW];
     load_planes<NW>(rd, s, lo, hi, nm);  // every lane reads the same (LDS-staged) words
     u32 v1[NW], P1[NW], P2[NW], P3[NW];
@@ -781,31 +798,49 @@ __attribute__((noinline)) __device__ double lane_bounds(const ReadRef &rd, u32 s
     }
     const int k = gmin + (int) lane_id();
     const u32 ku = (u32) k;
-    // V_k[i] = AND_{t<k} v1[i+t] by binary decomposition of k over A_b = AND of b consecutive bases
-    u32 V[NW], A[NW];
+    u32 V[NW];
+    u32 anyn = 0;
 #pragma unroll
     for (int j = 0; j < NW; j++) {
-        V[j] = 0xffffffffu;
-        A[j] = v1[j];
+        int bits = L - 32 * j;
+        u32 lm = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+        anyn |= nm[j] & lm;
     }
-    u32 off = 0;
+    if (anyn == 0) {
+        // no N in the segment (wave-uniform: every lane sees the same segment): V_k = the L-k+1 lowest bits
+        const int wbits = L - k + 1;
 #pragma unroll
-    for (int b = 1; b <= 64; b <<= 1) {
-        if (b > 1) {  // A_b = A_{b/2} & (A_{b/2} >> b/2)
-            u32 T2[NW];
-#pragma unroll
-            for (int j = 0; j < NW; j++) T2[j] = A[j] & shr_var_word<NW>(A, j, (u32) (b / 2));
-#pragma unroll
-            for (int j = 0; j < NW; j++) A[j] = T2[j];
+        for (int j = 0; j < NW; j++) {
+            const int bits = wbits - 32 * j;
+            V[j] = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
         }
-        if (b <= gmax) {  // wave-uniform
-            const bool take = (ku & (u32) b) != 0;
+    } else {
+        // V_k[i] = AND_{t<k} v1[i+t] by binary decomposition of k over A_b = AND of b consecutive bases
+        u32 A[NW];
 #pragma unroll
-            for (int j = 0; j < NW; j++) {
-                const u32 sh = shr_var_word<NW>(A, j, off);
-                V[j] &= take ? sh : 0xffffffffu;
+        for (int j = 0; j < NW; j++) {
+            V[j] = 0xffffffffu;
+            A[j] = v1[j];
+        }
+        u32 off = 0;
+#pragma unroll
+        for (int b = 1; b <= 64; b <<= 1) {
+            if (b > 1) {  // A_b = A_{b/2} & (A_{b/2} >> b/2)
+                u32 T2[NW];
+#pragma unroll
+                for (int j = 0; j < NW; j++) T2[j] = A[j] & shr_var_word<NW>(A, j, (u32) (b / 2));
+#pragma unroll
+                for (int j = 0; j < NW; j++) A[j] = T2[j];
             }
-            off += take ? (u32) b : 0u;
+            if (b <= gmax) {  // wave-uniform
+                const bool take = (ku & (u32) b) != 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) {
+                    const u32 sh = shr_var_word<NW>(A, j, off);
+                    V[j] &= take ? sh : 0xffffffffu;
+                }
+                off += take ? (u32) b : 0u;
+            }
         }
     }
     u32 c000 = 0, c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0, count = 0;
@@ -814,6 +849,8 @@ __attribute__((noinline)) __device__ double lane_bounds(const ReadRef &rd, u32 s
         const u32 F1 = P1[j] ^ shr_var_word<NW>(P1, j, ku), F2 = P2[j] ^ shr_var_word<NW>(P2, j, ku);
         const u32 F3 = P3[j] ^ shr_var_word<NW>(P3, j, ku);
         const u32 v = V[j];
+        out.V[j] = v;
+        out.E[j] = ~((lo[j] ^ shr_var_word<NW>(lo, j, ku)) | (hi[j] ^ shr_var_word<NW>(hi, j, ku)));
         const u32 a1 = v & F1, a0 = v ^ a1;
         const u32 a11 = a1 & F2, a10 = a1 ^ a11, a01 = a0 & F2, a00 = a0 ^ a01;
         const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
@@ -828,8 +865,8 @@ __attribute__((noinline)) __device__ double lane_bounds(const ReadRef &rd, u32 s
         c000 += __popc(a00 ^ b001);
     }
     const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
-    if (k > gmax || k >= 64 || count == 0) return k >= 64 && k <= gmax ? 2.0 : 0.0;  // k = 64 is not bounded here: never prune it
-    return (double) m8 / (double) count;
+    // k = 64 is not bounded here (shift amounts stay below 64): never prune it
+    out.ub = (k > gmax || k >= 64 || count == 0) ? ((k >= 64 && k <= gmax) ? 2.0 : 0.0) : (double) m8 / (double) count;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -842,6 +879,13 @@ struct Decision {
     u64 sh, sl;   // MAX_SEQ at those k (repeat_seq, kmer.cpp:2260-2262)
 };
 
+// bits j-1 for every multiple j <= 64 of k
+__device__ __forceinline__ u64 multiples_mask(int k) {
+    u64 m = 0;
+    for (int j = k; j <= 64; j += k) m |= 1ull << (j - 1);
+    return m;
+}
+
 __device__ __forceinline__ bool divides_any(int k, u64 accepted) {
     while (accepted) {
         const int tk = __ffsll((long long) accepted);  // bit tk-1 -> k value tk
@@ -853,41 +897,76 @@ __device__ __forceinline__ bool divides_any(int k, u64 accepted) {
 
 // selection loops of k_mer_check, kmer.cpp:2221-2258, run online over ascending
 // candidate k (non-candidates have frequency < LOW and can never be accepted)
-// ub: per-lane bound of lane_bounds() (lane l <-> k = MIN_MER + l), or NaN-free negative value "no bounds"
-template <bool HAVE_UB>
-__device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, double ub) {
+// M: per-lane knowledge of lane_bounds() (lane l <-> k = MIN_MER + l); ignored when NW == 0
+template <int NW>
+__device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, const LaneMasks<(NW > 0 ? NW : 1)> &M) {
+    constexpr bool HAVE_UB = NW > 0;
+    constexpr int NWB = NW > 0 ? NW : 1;
     Decision d;
     d.kh = d.kl = 0;
     d.sh = d.sl = 0;
     double tf_low = 0.0, tf_high = 0.0;
-    u64 acc_low = 0, acc_high = 0;
-    for (int k = kmin; k <= kmax; k++) {
-        if (!((cand >> (k - 1)) & 1ull)) continue;
-        // a multiple of an accepted k is never accepted and never moves the running
-        // frequency (kmer.cpp:2225-2236), so a k closed in both loops needs no evaluation
-        const bool lo_open = !divides_any(k, acc_low), hi_open = !divides_any(k, acc_high);
+    // closed_*: bit k-1 set <=> k is a multiple of a k already accepted in that loop.  Such a k is
+    // never accepted and never moves the running frequency (kmer.cpp:2225-2236).
+    u64 closed_low = 0, closed_high = 0;
+    u64 todo = cand & all_k_mask(kmin, kmax);
+    while (todo) {
+        const int k = __ffsll((long long) todo);  // bit k-1 -> k, ascending
+        todo &= todo - 1;
+        const bool lo_open = !((closed_low >> (k - 1)) & 1ull), hi_open = !((closed_high >> (k - 1)) & 1ull);
         if (!lo_open && !hi_open) continue;
         const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
         const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
+        KStat st;
         if (HAVE_UB) {
+            const int src = k - P.min_mer;
             // MAX <= maxbucket and IEEE division is monotone in the numerator: f <= bound < need
-            if (readlane_f64(ub, k - P.min_mer) < need) continue;
+            if (readlane_f64(M.ub, src) < need) continue;
+            // the window masks of this k were computed bit-parallel by lane `src`: fetch them
+            // instead of walking the windows (phase A of eval_k)
+            st.count = st.maxc = st.n_items = 0;
+            st.maxseq = 0;
+            st.pruned = false;
+            const int W = L - k + 1;
+            if (W > 0) {
+                __syncthreads();
+                u64 *vm = sm_vmask(sm), *em = sm_emask(sm);
+                const int nq = (NWB + 1) / 2;
+#pragma unroll
+                for (int q = 0; q < nq; q++) {
+                    const u32 v0 = (u32) __builtin_amdgcn_readlane((int) M.V[2 * q], src);
+                    const u32 e0 = (u32) __builtin_amdgcn_readlane((int) M.E[2 * q], src);
+                    const u32 v1 = 2 * q + 1 < NWB ? (u32) __builtin_amdgcn_readlane((int) M.V[2 * q + 1 < NWB ? 2 * q + 1 : 0], src) : 0u;
+                    const u32 e1 = 2 * q + 1 < NWB ? (u32) __builtin_amdgcn_readlane((int) M.E[2 * q + 1 < NWB ? 2 * q + 1 : 0], src) : 0u;
+                    if (lane_id() == 0) {
+                        vm[q] = ((u64) v1 << 32) | v0;
+                        em[q] = ((u64) e1 << 32) | e0;
+                    }
+                }
+                if (lane_id() == 0) {
+                    vm[nq] = 0;
+                    em[nq] = 0;
+                }
+                __syncthreads();
+                eval_runs(sm, W, k, st);
+            }
+        } else {
+            st = eval_k(sm, L, k, need);
         }
-        const KStat st = eval_k(sm, L, k, HAVE_UB ? 0.0 : need);
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
         if (is_homopolymer(st.maxseq, k)) continue;
         if (lo_open && f >= thr_lo) {
             d.kl = k;
             tf_low = f;
-            acc_low |= 1ull << (k - 1);
+            closed_low |= multiples_mask(k);
             d.sl = st.maxseq;
         }
         if (hi_open && f >= thr_hi) {
             d.kh = k;
             tf_high = f;
-            acc_high |= 1ull << (k - 1);
+            closed_high |= multiples_mask(k);
             d.sh = st.maxseq;
         }
     }
@@ -925,14 +1004,14 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
     Decision left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
     if (sL.valid) {
         load_segment(sm, rd, sL.start, sL.len);
-        double ubL = 0, ubR = 0;
+        LaneMasks<NWB> mL, mR;
         if (UB) {
-            ubL = lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer);
-            ubR = lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer);
+            lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
+            lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
         }
-        left = decide<UB>(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0], ubL);
+        left = decide<NW>(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0], mL);
         load_segment(sm, rd, sR.start, sR.len);
-        right = decide<UB>(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1], ubR);
+        right = decide<NW>(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1], mR);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
@@ -976,8 +1055,9 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
     const bool lh = left.kl == 0 && right.kl == 0;
     if (sW.valid && (hh || lh)) {  // kmer.cpp:168-171
         load_segment(sm, rd, 0, (u32) n);
-        const double ubW = UB ? lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer) : 0.0;
-        const Decision w = decide<UB>(sm, P, n, sW.kmin, sW.kmax, it.cand[2], ubW);
+        LaneMasks<NWB> mW;
+        if (UB) lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer, mW);
+        const Decision w = decide<NW>(sm, P, n, sW.kmin, sW.kmax, it.cand[2], mW);
         const bool rec_h = hh && w.kh > 0, rec_l = lh && w.kl > 0;
         if (rec_h && rec_l && w.kh == w.kl) {
             record(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
@@ -998,8 +1078,9 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B,
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
     load_segment(sm, rd, 0, s.len);
-    const double ub = UB ? lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer) : 0.0;
-    const Decision d = decide<UB>(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0], ub);
+    LaneMasks<NWB> m;
+    if (UB) lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer, m);
+    const Decision d = decide<NW>(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0], m);
     if (d.kh > 0 && d.kh == d.kl) {
         record(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
     } else {
@@ -1041,8 +1122,9 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         u32 st, sl;
         long_slice(t, mid, bonus, SL, st, sl);
         load_segment(sm, rd, st, sl);
-        const double ub = UB ? lane_bounds<NWB>(rd, st, (int) sl, P.min_mer, P.max_mer) : 0.0;
-        return decide<UB>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, ub);
+        LaneMasks<NWB> m;
+        if (UB) lane_bounds<NWB>(rd, st, (int) sl, P.min_mer, P.max_mer, m);
+        return decide<NW>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m);
     };
     auto slice_len = [&](int t) { return (int) (SL + (t == mid ? bonus : 0)); };
     // pass 1: forward chain (kmer.cpp:797-817)
@@ -1144,8 +1226,9 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const Segment sg = seg_of(slot);
         const ReadRef &r = sg.mate ? r1 : r0;
         load_segment(sm, r, sg.start, sg.len);
-        const double ub = UB ? lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer) : 0.0;
-        return decide<UB>(sm, P, (int) sg.len, sg.kmin, sg.kmax, itp->cand[slot], ub);  // global load: slot is dynamic
+        LaneMasks<NWB> m;
+        if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
+        return decide<NW>(sm, P, (int) sg.len, sg.kmin, sg.kmax, itp->cand[slot], m);  // global load: slot is dynamic
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
         if (k > 0 && n_int < 32) {
@@ -1288,13 +1371,18 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
     sm.rawwords = rawwords;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
-    // dynamic self-scheduling: reads differ 10x in cost, so waves pull the next item from a
-    // device counter (wl_count[1], zeroed with wl_count[0]) instead of a static stride
+    // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from a device counter
+    // (wl_count[1], zeroed with wl_count[0]) instead of a static stride.  One returning atomic on a
+    // single word saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue"), which
+    // alone would cost 2 ms per 176 k reads: pull kChunk consecutive items per atomic.
+    constexpr u32 kChunk = 8;
     for (;;) {
-        u32 w = 0;
-        if (lane_id() == 0) w = atomicAdd(&wl_count[1], 1u);
-        w = rfl(w);
-        if (w >= n) break;
+        u32 w0 = 0;
+        if (lane_id() == 0) w0 = atomicAdd(&wl_count[1], kChunk);
+        w0 = rfl(w0);
+        if (w0 >= n) break;
+        const u32 w1 = w0 + kChunk < n ? w0 + kChunk : n;
+        for (u32 w = w0; w < w1; w++) {
         const WorkItem it = wl[w];
         // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
         if (MODE == TREW_MODE_SHORT)
@@ -1306,6 +1394,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         else
             run_pair<NW>(sm, P, B, T, &wl[w]);
         __syncthreads();
+        }
     }
 }
 
