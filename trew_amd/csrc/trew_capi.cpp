@@ -26,7 +26,7 @@ struct Slot {
     u32 *d_words = nullptr;
     u32 *d_offsets = nullptr;
     u32 *d_lengths = nullptr;
-    WorkItem *d_wl = nullptr;
+    u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -168,7 +168,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         }
         if ((e = hipMalloc((void **) &s.d_offsets, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(offsets)", e);
         if ((e = hipMalloc((void **) &s.d_lengths, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(lengths)", e);
-        if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(WorkItem))) != hipSuccess) return bail("hipMalloc(worklist)", e);
+        if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 8)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
         if (p.mode == TREW_MODE_SEGMENT) {
             if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
@@ -312,7 +312,7 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
     HIPCHK(ctx, hipEventRecord(s.e0, s.stream));
-    HIPCHK(ctx, launch_filter(s.stream, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
+    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
     HIPCHK(ctx, hipEventRecord(s.e1, s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
@@ -426,7 +426,7 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
     if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 8, s.stream);
     if (e == hipSuccess)
-        e = launch_filter(s.stream, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
+        e = launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
     if (e == hipSuccess) e = hipMemcpy(cand, d, bytes, hipMemcpyDeviceToHost);
     (void) hipFree(d);

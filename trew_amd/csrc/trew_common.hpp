@@ -38,13 +38,7 @@ struct DevBatch {
     u64 n_units;  // reads, or pairs in pair mode
 };
 
-// one unit (read / pair) that survived the prefilter, with the candidate-k mask
-// of each of its segments: bit (k-1) set <=> k may reach the low baseline.
-struct WorkItem {
-    u32 unit;
-    u32 pad;
-    u64 cand[kMaxSlots];
-};
+// the worklist is a plain array of unit indices (reads / pairs) that survived the prefilter
 
 struct DevTable {
     u64 *keys;    // 0 = empty

@@ -271,80 +271,97 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 }
 
 
+constexpr u32 kStage = 1024;  // unit indices a block stages in LDS before one global append
+
+// Persistent blocks, grid-stride over the reads.  Survivors are staged in LDS and appended to
+// the worklist with ONE global atomic per flush: a per-wave atomic on the single worklist
+// counter caps at ~88 appends/us on MI355X (MI355X_MICROARCH.md "dequeue"), which was as long
+// as the whole k loop.
 template <int NW>
-__global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, WorkItem *wl, u32 *wl_count, u32 wl_cap,
+__global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u32 *wl, u32 *wl_count, u32 wl_cap,
                                                      u64 *dbg_masks, int dbg_slots, int max_seg) {
-    const u64 unit = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = unit < B.n_units;
-    ReadRef rd[2];
-    rd[0].w = B.words;
-    rd[0].len = 0;
-    rd[0].nw = 0;
-    rd[1] = rd[0];
-    if (active) {
-        if (P.mode == TREW_MODE_PAIR) {
-            rd[0] = get_read(B, 2 * unit);
-            rd[1] = get_read(B, 2 * unit + 1);
-        } else {
-            rd[0] = get_read(B, unit);
+    __shared__ u32 stage[kStage];
+    __shared__ u32 stage_n, flush_base;
+    if (threadIdx.x == 0) stage_n = 0;
+    __syncthreads();
+    auto flush = [&]() {  // block-uniform
+        const u32 n = stage_n;
+        if (n) {
+            if (threadIdx.x == 0) flush_base = atomicAdd(wl_count, n);
+            __syncthreads();
+            const u32 fb = flush_base;
+            for (u32 i = threadIdx.x; i < n; i += blockDim.x)
+                if (fb + i < wl_cap) wl[fb + i] = stage[i];
+            __syncthreads();
+            if (threadIdx.x == 0) stage_n = 0;
         }
-    }
-    u64 masks[kMaxSlots];
+        __syncthreads();
+    };
     const int nslots = mode_slots(P.mode);
-    u64 any = 0;
+    for (u64 base = (u64) blockIdx.x * blockDim.x; base < B.n_units; base += (u64) gridDim.x * blockDim.x) {
+        const u64 unit = base + threadIdx.x;
+        const bool active = unit < B.n_units;
+        ReadRef rd[2];
+        rd[0].w = B.words;
+        rd[0].len = 0;
+        rd[0].nw = 0;
+        rd[1] = rd[0];
+        if (active) {
+            if (P.mode == TREW_MODE_PAIR) {
+                rd[0] = get_read(B, 2 * unit);
+                rd[1] = get_read(B, 2 * unit + 1);
+            } else {
+                rd[0] = get_read(B, unit);
+            }
+        }
+        u64 any = 0;
 #pragma unroll
-    for (int slot = 0; slot < kMaxSlots; slot++) {
-        masks[slot] = 0;
-        if (slot < nslots) {
-            Segment sg = get_segment(P.mode, slot, rd[0].len, rd[1].len, P.min_mer, P.max_mer, P.slice_len);
-            const bool ok = active && sg.valid && sg.len <= (u32) (32 * NW - 1);
-            if (__any(ok)) {
-                u32 lo[NW], hi[NW], nm[NW];
-                const ReadRef &r = sg.mate ? rd[1] : rd[0];
-                if (ok) {
-                    load_planes<NW>(r, sg.start, lo, hi, nm);
-                } else {
+        for (int slot = 0; slot < kMaxSlots; slot++) {
+            if (slot < nslots) {
+                u64 mask = 0;
+                Segment sg = get_segment(P.mode, slot, rd[0].len, rd[1].len, P.min_mer, P.max_mer, P.slice_len);
+                const bool ok = active && sg.valid && sg.len <= (u32) (32 * NW - 1);
+                if (__any(ok)) {
+                    u32 lo[NW], hi[NW], nm[NW];
+                    const ReadRef &r = sg.mate ? rd[1] : rd[0];
+                    if (ok) {
+                        load_planes<NW>(r, sg.start, lo, hi, nm);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < NW; j++) {
-                        lo[j] = hi[j] = 0;
-                        nm[j] = 0xffffffffu;
+                        for (int j = 0; j < NW; j++) {
+                            lo[j] = hi[j] = 0;
+                            nm[j] = 0xffffffffu;
+                        }
                     }
+                    u64 m;
+                    if (P.flags & TREW_FLAG_NO_FILTER)
+                        m = all_k_mask(sg.kmin, sg.kmax);
+                    else
+                        m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer,
+                                               (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer, max_seg, P.lowf);
+                    mask = ok ? m : 0ull;
                 }
-                u64 m;
-                if (P.flags & TREW_FLAG_NO_FILTER)
-                    m = all_k_mask(sg.kmin, sg.kmax);
-                else
-                    m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer,
-                                           (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer, max_seg, P.lowf);
-                masks[slot] = ok ? m : 0ull;
-            }
-            // a segment too long for this instantiation must never be dropped silently
-            if (active && sg.valid && sg.len > (u32) (32 * NW - 1)) masks[slot] = all_k_mask(sg.kmin, sg.kmax);
-            any |= masks[slot];
-            if (dbg_masks && active && slot < dbg_slots) dbg_masks[unit * (u64) dbg_slots + slot] = masks[slot];
-        }
-    }
-    // wave-aggregated append to the worklist
-    const bool flag = active && any != 0;
-    const u64 bal = __ballot(flag);
-    if (bal) {
-        const u32 lane = lane_id();
-        u32 base = 0;
-        if (lane == (u32) __ffsll((long long) bal) - 1u) base = atomicAdd(wl_count, (u32) __popcll(bal));
-        base = __shfl(base, __ffsll((long long) bal) - 1);
-        if (flag) {
-            const u32 rank = (u32) __popcll(bal & ((1ull << lane) - 1ull));
-            const u32 idx = base + rank;
-            if (idx < wl_cap) {
-                WorkItem it;
-                it.unit = (u32) unit;
-                it.pad = 0;
-#pragma unroll
-                for (int s = 0; s < kMaxSlots; s++) it.cand[s] = masks[s];
-                wl[idx] = it;
+                // a segment too long for this instantiation must never be dropped silently
+                if (active && sg.valid && sg.len > (u32) (32 * NW - 1)) mask = all_k_mask(sg.kmin, sg.kmax);
+                any |= mask;
+                if (dbg_masks && active && slot < dbg_slots) dbg_masks[unit * (u64) dbg_slots + slot] = mask;
             }
         }
+        // wave-aggregated append to the block's LDS stage
+        const bool flag = active && any != 0;
+        const u64 bal = __ballot(flag);
+        if (bal) {
+            const u32 lane = lane_id();
+            const int leader = __ffsll((long long) bal) - 1;
+            u32 sb = 0;
+            if ((int) lane == leader) sb = atomicAdd(&stage_n, (u32) __popcll(bal));
+            sb = __shfl(sb, leader);
+            if (flag) stage[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = (u32) unit;  // < kStage: flushed below when > kStage-256
+        }
+        __syncthreads();
+        if (stage_n > kStage - 256u) flush();
     }
+    flush();
 }
 
 // ------------------------------------------------------------------ count table
@@ -993,10 +1010,10 @@ __device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int 
 
 // buffer_task, kmer.cpp:111-173
 template <int NW>
-__device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+__device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
+    const ReadRef rd = stage_read(sm, get_read(B, unit), 0);
     const int n = (int) rd.len;
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
@@ -1009,9 +1026,9 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
             lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
             lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
         }
-        left = decide<NW>(sm, P, (int) sL.len, sL.kmin, sL.kmax, it.cand[0], mL);
+        left = decide<NW>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL);
         load_segment(sm, rd, sR.start, sR.len);
-        right = decide<NW>(sm, P, (int) sR.len, sR.kmin, sR.kmax, it.cand[1], mR);
+        right = decide<NW>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
@@ -1057,7 +1074,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
         load_segment(sm, rd, 0, (u32) n);
         LaneMasks<NWB> mW;
         if (UB) lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer, mW);
-        const Decision w = decide<NW>(sm, P, n, sW.kmin, sW.kmax, it.cand[2], mW);
+        const Decision w = decide<NW>(sm, P, n, sW.kmin, sW.kmax, ~0ull, mW);
         const bool rec_h = hh && w.kh > 0, rec_l = lh && w.kl > 0;
         if (rec_h && rec_l && w.kh == w.kl) {
             record(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
@@ -1070,17 +1087,17 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
 
 // TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
 template <int NW>
-__device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it,
+__device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit,
                             const SegResults &R) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = stage_read(sm, get_read(B, it.unit), 0);
+    const ReadRef rd = stage_read(sm, get_read(B, unit), 0);
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
     load_segment(sm, rd, 0, s.len);
     LaneMasks<NWB> m;
     if (UB) lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer, m);
-    const Decision d = decide<NW>(sm, P, (int) s.len, s.kmin, s.kmax, it.cand[0], m);
+    const Decision d = decide<NW>(sm, P, (int) s.len, s.kmin, s.kmax, ~0ull, m);
     if (d.kh > 0 && d.kh == d.kl) {
         record(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
     } else {
@@ -1088,10 +1105,10 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B,
         record(sm, T, (int) s.len, d.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
     }
     if (lane_id() == 0 && R.k_high) {
-        R.k_high[it.unit] = d.kh;
-        R.k_low[it.unit] = d.kl;
-        R.seq_high[it.unit] = d.sh;
-        R.seq_low[it.unit] = d.sl;
+        R.k_high[unit] = d.kh;
+        R.k_low[unit] = d.kl;
+        R.seq_high[unit] = d.sh;
+        R.seq_low[unit] = d.sl;
     }
 }
 
@@ -1108,10 +1125,10 @@ __device__ __forceinline__ void long_slice(int t, int mid, int bonus, int SL, u3
 // it runs twice: pass 1 decides, pass 2 re-decides the recorded slices and emits.  The
 // backward walk records straight into result.backward (kmer.cpp:840).
 template <int NW>
-__device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem &it) {
+__device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = get_read(B, it.unit);
+    const ReadRef rd = get_read(B, unit);
     const int SL = P.slice_len;
     const int len = (int) rd.len;
     const int snum = len / SL;
@@ -1131,7 +1148,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     int si[2] = {1, 1}, kmer[2] = {0, 0}, last_rec[2] = {0, 0};
     bool rend[2] = {false, false};
     for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {
-        const Decision d = slice_decide(ti, ti == 1 ? it.cand[0] : (ti == snum ? it.cand[1] : allk));
+        const Decision d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
         const int tk[2] = {d.kh, d.kl};
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -1152,7 +1169,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const u32 th = canon_h ? TREW_TABLE_BOTH_HIGH : TREW_TABLE_FORWARD_HIGH;
         const u32 tl = canon_l ? TREW_TABLE_BOTH_LOW : TREW_TABLE_FORWARD_LOW;
         for (int ti = 1; ti <= upto; ti++) {
-            const Decision d = slice_decide(ti, ti == 1 ? it.cand[0] : (ti == snum ? it.cand[1] : allk));
+            const Decision d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
             const bool rh = ti <= last_rec[0] && d.kh > 0, rl = ti <= last_rec[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl && canon_h == canon_l) {
                 record(sm, T, slice_len(ti), d.kh, (1u << th) | (1u << tl), canon_h);
@@ -1168,7 +1185,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         kmer[0] = kmer[1] = 0;
         rend[0] = rend[1] = false;
         for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
-            const Decision d = slice_decide(tj, tj == snum ? it.cand[1] : (tj == 1 ? it.cand[0] : allk));
+            const Decision d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk));
             const bool rh = !rend[0] && d.kh > 0, rl = !rend[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl) {
                 record(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
@@ -1209,10 +1226,10 @@ __device__ __forceinline__ u64 dir_seq(int i, int k, u64 seq, bool is_for) {
 // the whole-read block (kmer.cpp:722-723; SURVEY G1 -- the one documented divergence from the
 // 64-bit branch, whose stale map makes results depend on thread scheduling).
 template <int NW>
-__device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, const WorkItem *itp) {
+__device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit_in) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const u64 unit = itp->unit;
+    const u64 unit = unit_in;
     const ReadRef r0 = stage_read(sm, get_read(B, 2ull * unit), 0);
     const ReadRef r1 = stage_read(sm, get_read(B, 2ull * unit + 1), 1);
     const int n1 = (int) r0.len, n2 = (int) r1.len;
@@ -1228,7 +1245,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         load_segment(sm, r, sg.start, sg.len);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
-        return decide<NW>(sm, P, (int) sg.len, sg.kmin, sg.kmax, itp->cand[slot], m);  // global load: slot is dynamic
+        return decide<NW>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
         if (k > 0 && n_int < 32) {
@@ -1364,7 +1381,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
 // NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
 // NW == 0: long segments, pruning happens inside eval_k instead.
 template <int NW, int MODE>
-__global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const WorkItem *wl,
+__global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const u32 *wl,
                                                    u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
     ExactSmem sm;
     sm.cap = cap;
@@ -1383,7 +1400,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         if (w0 >= n) break;
         const u32 w1 = w0 + kChunk < n ? w0 + kChunk : n;
         for (u32 w = w0; w < w1; w++) {
-        const WorkItem it = wl[w];
+        const u32 it = wl[w];
         // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
         if (MODE == TREW_MODE_SHORT)
             run_short<NW>(sm, P, B, T, it);
@@ -1392,7 +1409,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         else if (MODE == TREW_MODE_LONG)
             run_long<NW>(sm, P, B, T, it);
         else
-            run_pair<NW>(sm, P, B, T, &wl[w]);
+            run_pair<NW>(sm, P, B, T, it);
         __syncthreads();
         }
     }
@@ -1485,14 +1502,15 @@ int pick_nw(u32 max_seg_len) {
     return 32;
 }
 
-hipError_t launch_filter(hipStream_t st, u32 max_seg_len, const DevParams &P, const DevBatch &B, WorkItem *wl, u32 *wl_count,
+hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevParams &P, const DevBatch &B, u32 *wl, u32 *wl_count,
                          u32 wl_cap, u64 *dbg_masks, int dbg_slots) {
     const int nw = pick_nw(max_seg_len);
     const int max_seg = (int) std::min<u32>(max_seg_len, (u32) (32 * nw - 1));
     if (B.n_units == 0) return hipSuccess;
     const u32 threads = 256;
-    const u64 blocks = (B.n_units + threads - 1) / threads;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    u64 blocks = (B.n_units + threads - 1) / threads;
+    const u64 persistent = (u64) n_cu * 8ull;  // grid-stride blocks, a few per CU
+    if (blocks > persistent) blocks = persistent;
     dim3 g((u32) blocks), b(threads);
     switch (nw) {
     case 3: hipLaunchKernelGGL(filter_kernel<3>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
@@ -1506,14 +1524,14 @@ hipError_t launch_filter(hipStream_t st, u32 max_seg_len, const DevParams &P, co
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords) { return exact_lds_bytes(cap, rawwords); }
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
-                        const WorkItem *wl, u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
+                        const u32 *wl, u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
     const u32 lds = exact_lds_bytes(cap, rawwords);
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
     const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
-    typedef void (*kern_t)(DevParams, DevBatch, DevTable, const WorkItem *, u32 *, u32, SegResults, u32, u32);
+    typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
 #define TREW_PICK_MODE(NWV)                                                           \
     switch (P.mode) {                                                                 \
