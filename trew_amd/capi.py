@@ -258,9 +258,10 @@ class TrewHip:
                   "trew_hip_filter_masks")
         return cand[: units * slots_per_read].reshape(units, slots_per_read)
 
-    def last_timing(self, slot=0):
+    def last_timing(self, slot=0, want_flagged=True):
         a, b, n = C.c_float(), C.c_float(), C.c_uint64()
-        self._chk(self.lib.trew_hip_last_timing(self.ctx, slot, C.byref(a), C.byref(b), C.byref(n)), "trew_hip_last_timing")
+        self._chk(self.lib.trew_hip_last_timing(self.ctx, slot, C.byref(a), C.byref(b), C.byref(n) if want_flagged else None),
+                  "trew_hip_last_timing")
         return a.value, b.value, n.value
 
     # ---- device memory ----

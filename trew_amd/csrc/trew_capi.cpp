@@ -35,6 +35,7 @@ struct Slot {
 };
 
 std::string g_init_error;
+constexpr size_t kWlCountBytes = (32 + 8 * 32) * 4;  // [0] worklist size, then 8 queue heads on separate 128-B lines
 
 }  // namespace
 
@@ -169,7 +170,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         if ((e = hipMalloc((void **) &s.d_offsets, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(offsets)", e);
         if ((e = hipMalloc((void **) &s.d_lengths, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(lengths)", e);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
-        if ((e = hipMalloc((void **) &s.d_wl_count, 8)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
+        if ((e = hipMalloc((void **) &s.d_wl_count, kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
         if (p.mode == TREW_MODE_SEGMENT) {
             if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
@@ -303,7 +304,7 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     s.n_units = db.n_units;
     s.timed = false;
     if (db.n_units == 0) return 0;
-    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, 8, s.stream));
+    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, kWlCountBytes, s.stream));
     if (ctx->p.mode == TREW_MODE_SEGMENT) {
         HIPCHK(ctx, hipMemsetAsync(s.res.k_high, 0, db.n_reads * 4, s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.res.k_low, 0, db.n_reads * 4, s.stream));
@@ -424,7 +425,7 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     const u64 bytes = db.n_units * (u64) slots_per_read * 8ull;
     HIPCHK(ctx, hipMalloc((void **) &d, bytes));
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
-    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, 8, s.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, kWlCountBytes, s.stream);
     if (e == hipSuccess)
         e = launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
@@ -442,7 +443,7 @@ extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filte
     if (!s.timed) return fail(ctx, "no timed submit on this slot");
     if (ms_filter) HIPCHK(ctx, hipEventElapsedTime(ms_filter, s.e0, s.e1));
     if (ms_exact) HIPCHK(ctx, hipEventElapsedTime(ms_exact, s.e1, s.e2));
-    if (n_flagged) {
+    if (n_flagged) {  // optional: costs one blocking 4-byte copy
         u32 c = 0;
         HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count, 4, hipMemcpyDeviceToHost));
         *n_flagged = c;

@@ -1388,16 +1388,23 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
     sm.rawwords = rawwords;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
-    // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from a device counter
-    // (wl_count[1], zeroed with wl_count[0]) instead of a static stride.  One returning atomic on a
-    // single word saturates at ~88 dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue"), which
-    // alone would cost 2 ms per 176 k reads: pull kChunk consecutive items per atomic.
-    constexpr u32 kChunk = 8;
-    for (;;) {
-        u32 w0 = 0;
-        if (lane_id() == 0) w0 = atomicAdd(&wl_count[1], kChunk);
-        w0 = rfl(w0);
-        if (w0 >= n) break;
+    // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from device counters
+    // instead of a static stride.  One returning atomic on a single word saturates at ~88
+    // dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue") -- 2 ms for 176 k reads -- so the
+    // queue head is sharded 8 ways (own cache line each; chunk c of shard s = global chunk 8c+s)
+    // and a wave whose shard runs dry steals from the next one.
+    constexpr u32 kChunk = 2, kShards = 8, kHeadStride = 32;
+    u32 *heads = wl_count + kHeadStride;
+    const u32 my = blockIdx.x & (kShards - 1);
+    for (u32 attempt = 0; attempt < kShards; attempt++) {
+        const u32 sh = (my + attempt) & (kShards - 1);
+        for (;;) {
+        u32 c = 0;
+        if (lane_id() == 0) c = atomicAdd(&heads[sh * kHeadStride], 1u);
+        c = rfl(c);
+        const u64 w0l = ((u64) c * kShards + sh) * kChunk;
+        if (w0l >= n) break;
+        const u32 w0 = (u32) w0l;
         const u32 w1 = w0 + kChunk < n ? w0 + kChunk : n;
         for (u32 w = w0; w < w1; w++) {
         const u32 it = wl[w];
@@ -1411,6 +1418,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         else
             run_pair<NW>(sm, P, B, T, it);
         __syncthreads();
+        }
         }
     }
 }
