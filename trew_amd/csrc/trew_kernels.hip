@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
     // dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue") -- 2 ms for 176 k reads -- so the
     // queue head is sharded 8 ways (own cache line each; chunk c of shard s = global chunk 8c+s)
     // and a wave whose shard runs dry steals from the next one.
-    constexpr u32 kChunk = 2, kShards = 8, kHeadStride = 32;
+    constexpr u32 kChunk = 1, kShards = 8, kHeadStride = 32;
     u32 *heads = wl_count + kHeadStride;
     const u32 my = blockIdx.x & (kShards - 1);
     for (u32 attempt = 0; attempt < kShards; attempt++) {
