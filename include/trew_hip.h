@@ -134,8 +134,9 @@ int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32
  * Diagnostic: used to test that the prefilter never drops a passing k. */
 int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *batch, uint64_t *cand, int slots_per_read);
 
-/* Kernel timings of the last submit on `slot` (HIP events on the slot's
- * stream), milliseconds; n_flagged = reads the prefilter passed to the exact kernel. */
+/* Mean kernel timings of the submits on `slot` since the previous call (HIP events on the
+ * slot's own stream, at most the last 128 submits), milliseconds; n_flagged (optional) = reads
+ * the prefilter passed to the exact kernel in the last submit. */
 int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filter, float *ms_exact, uint64_t *n_flagged);
 
 /* ---- host-side packing: the codes[] lookup of kmer.cpp:14-31 applied once per base ---- */

@@ -222,11 +222,14 @@ class TrewHip:
     def collect_rows(self, table=-1):
         """Rows of one table (or all, table=-1) as a structured numpy array (ROW_DTYPE)."""
         n = C.c_uint64(0)
-        self._chk(self.lib.trew_hip_collect(self.ctx, table, None, 0, C.byref(n)), "trew_hip_collect")
-        rows = np.zeros(max(1, n.value), dtype=ROW_DTYPE)
-        self._chk(self.lib.trew_hip_collect(self.ctx, table, C.cast(rows.ctypes.data, C.POINTER(Row)), n.value,
-                                            C.byref(n)), "trew_hip_collect")
-        return rows[: n.value]
+        cap = getattr(self, "_collect_cap", 1 << 16)
+        while True:  # one call when the guess holds; the table tells its size when it does not
+            rows = np.zeros(cap, dtype=ROW_DTYPE)
+            self._chk(self.lib.trew_hip_collect(self.ctx, table, C.cast(rows.ctypes.data, C.POINTER(Row)), cap,
+                                                C.byref(n)), "trew_hip_collect")
+            if n.value <= cap:
+                return rows[: n.value]
+            cap = self._collect_cap = int(n.value) + 1024
 
     def collect(self):
         """The six tables as {name: {(k, word): count}}."""

@@ -29,8 +29,12 @@ struct Slot {
     u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    bool timed = false;
+    // ring of (before filter, between, after exact) events: submits may be queued back to back
+    // on the slot's stream without a wait in between, each keeps its own timestamps
+    static constexpr int kRing = 128;
+    hipEvent_t ev[kRing][3] = {};
+    u64 n_submits = 0;   // submits since init
+    u64 n_reported = 0;  // submits already averaged by trew_hip_last_timing
     u64 n_units = 0;
 };
 
@@ -47,6 +51,10 @@ struct trew_hip_ctx {
     std::vector<Slot> slots;
     std::string err;
     int n_cu = 256;
+    // persistent scratch of trew_hip_collect (device-side compaction)
+    unsigned long long *d_collect_n = nullptr;
+    trew_hip_row *d_collect_rows = nullptr;
+    u64 collect_cap = 0;
 };
 
 #define HIPCHK(ctx, expr)                                                                         \
@@ -177,9 +185,9 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMalloc((void **) &s.res.seq_high, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.seq_low, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
         }
-        if ((e = hipEventCreate(&s.e0)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreate(&s.e1)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreate(&s.e2)) != hipSuccess) return bail("hipEventCreate", e);
+        for (int i = 0; i < Slot::kRing; i++)
+            for (int j = 0; j < 3; j++)
+                if ((e = hipEventCreate(&s.ev[i][j])) != hipSuccess) return bail("hipEventCreate", e);
     }
     *out = ctx;
     return 0;
@@ -199,14 +207,16 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
         if (s.res.k_low) (void) hipFree(s.res.k_low);
         if (s.res.seq_high) (void) hipFree(s.res.seq_high);
         if (s.res.seq_low) (void) hipFree(s.res.seq_low);
-        if (s.e0) (void) hipEventDestroy(s.e0);
-        if (s.e1) (void) hipEventDestroy(s.e1);
-        if (s.e2) (void) hipEventDestroy(s.e2);
+        for (int i = 0; i < Slot::kRing; i++)
+            for (int j = 0; j < 3; j++)
+                if (s.ev[i][j]) (void) hipEventDestroy(s.ev[i][j]);
         if (s.stream) (void) hipStreamDestroy(s.stream);
     }
     if (ctx->table.keys) (void) hipFree(ctx->table.keys);
     if (ctx->table.counts) (void) hipFree(ctx->table.counts);
     if (ctx->table.overflow) (void) hipFree(ctx->table.overflow);
+    if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
+    if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
     delete ctx;
 }
 
@@ -302,7 +312,6 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     DevBatch db;
     if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
     s.n_units = db.n_units;
-    s.timed = false;
     if (db.n_units == 0) return 0;
     HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, kWlCountBytes, s.stream));
     if (ctx->p.mode == TREW_MODE_SEGMENT) {
@@ -312,9 +321,10 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
         HIPCHK(ctx, hipMemsetAsync(s.res.seq_low, 0, db.n_reads * 8, s.stream));
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
-    HIPCHK(ctx, hipEventRecord(s.e0, s.stream));
+    hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
+    HIPCHK(ctx, hipEventRecord(ev[0], s.stream));
     HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
-    HIPCHK(ctx, hipEventRecord(s.e1, s.stream));
+    HIPCHK(ctx, hipEventRecord(ev[1], s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
@@ -323,8 +333,8 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     DevTable tbl = ctx->table;
     if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
     HIPCHK(ctx, launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, s.d_wl_count, wl_cap, s.res, cap, rawwords, max_seg));
-    HIPCHK(ctx, hipEventRecord(s.e2, s.stream));
-    s.timed = true;
+    HIPCHK(ctx, hipEventRecord(ev[2], s.stream));
+    s.n_submits++;
     return 0;
 }
 
@@ -349,23 +359,24 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     u32 ovf = 0;
     HIPCHK(ctx, hipMemcpy(&ovf, ctx->table.overflow, 4, hipMemcpyDeviceToHost));
     if (ovf) return fail(ctx, "device count table overflow: raise table_log2_slots");
-    // compact on the device, copy only the occupied rows
+    // compact on the device, copy only the occupied rows (scratch buffers persist across calls)
     const u64 dcap = rows ? cap : 0;
-    unsigned long long *d_n = nullptr;
-    trew_hip_row *d_rows = nullptr;
-    HIPCHK(ctx, hipMalloc((void **) &d_n, 8));
-    hipError_t e = hipSuccess;
-    if (dcap) e = hipMalloc((void **) &d_rows, dcap * sizeof(trew_hip_row));
+    if (!ctx->d_collect_n) HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_n, 8));
+    if (dcap > ctx->collect_cap) {
+        if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
+        ctx->d_collect_rows = nullptr;
+        ctx->collect_cap = 0;
+        const u64 want = std::max<u64>(dcap, 1ull << 16);
+        HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_rows, want * sizeof(trew_hip_row)));
+        ctx->collect_cap = want;
+    }
     hipStream_t st = ctx->slots[0].stream;
-    if (e == hipSuccess) e = hipMemsetAsync(d_n, 0, 8, st);
-    if (e == hipSuccess) e = launch_compact(st, ctx->table, ctx->table_slots, table, d_rows, dcap, d_n);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_collect_n, 0, 8, st));
+    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, table, ctx->d_collect_rows, dcap, ctx->d_collect_n));
     unsigned long long n = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&n, d_n, 8, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess && dcap && n) e = hipMemcpy(rows, d_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost);
-    (void) hipFree(d_n);
-    if (d_rows) (void) hipFree(d_rows);
-    HIPCHK(ctx, e);
+    HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_collect_n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (dcap && n) HIPCHK(ctx, hipMemcpy(rows, ctx->d_collect_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
     *n_rows = n;
     return 0;
 }
@@ -440,9 +451,23 @@ extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filte
     if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
     if (int rc = trew_hip_wait(ctx, slot)) return rc;
     Slot &s = ctx->slots[(size_t) slot];
-    if (!s.timed) return fail(ctx, "no timed submit on this slot");
-    if (ms_filter) HIPCHK(ctx, hipEventElapsedTime(ms_filter, s.e0, s.e1));
-    if (ms_exact) HIPCHK(ctx, hipEventElapsedTime(ms_exact, s.e1, s.e2));
+    // mean over the submits since the previous call (at most the last kRing of them)
+    u64 first = s.n_reported;
+    if (s.n_submits - first > (u64) Slot::kRing) first = s.n_submits - Slot::kRing;
+    if (first == s.n_submits) return fail(ctx, "no timed submit on this slot since the last query");
+    double sf = 0, se = 0;
+    for (u64 i = first; i < s.n_submits; i++) {
+        float a = 0, b = 0;
+        hipEvent_t *ev = s.ev[i % Slot::kRing];
+        HIPCHK(ctx, hipEventElapsedTime(&a, ev[0], ev[1]));
+        HIPCHK(ctx, hipEventElapsedTime(&b, ev[1], ev[2]));
+        sf += a;
+        se += b;
+    }
+    const double cnt = (double) (s.n_submits - first);
+    s.n_reported = s.n_submits;
+    if (ms_filter) *ms_filter = (float) (sf / cnt);
+    if (ms_exact) *ms_exact = (float) (se / cnt);
     if (n_flagged) {  // optional: costs one blocking 4-byte copy
         u32 c = 0;
         HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count, 4, hipMemcpyDeviceToHost));

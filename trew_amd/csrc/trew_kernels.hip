@@ -1555,8 +1555,19 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     default: TREW_PICK_MODE(0) break;
     }
 #undef TREW_PICK_MODE
+    // the occupancy query is not free: remember the last answer
+    static kern_t cached_fn = nullptr;
+    static u32 cached_lds = 0;
+    static int cached_per_cu = 0;
     int per_cu = 8;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fn, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+    if (cached_fn == fn && cached_lds == lds) {
+        per_cu = cached_per_cu;
+    } else {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fn, 64, lds) != hipSuccess || per_cu < 1) per_cu = 8;
+        cached_fn = fn;
+        cached_lds = lds;
+        cached_per_cu = per_cu;
+    }
     per_cu = per_cu > 32 ? 32 : per_cu;
     const u32 grid = (u32) std::min<u64>((u64) n_cu * (u64) per_cu, std::max<u64>(n_units, 1));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords);
