@@ -60,7 +60,7 @@ enum {
  * (kmer.h:55-63, set in trew.cpp:165-172, 246-253). */
 typedef struct {
     int32_t min_mer;          /* MIN_MER, >= 3 (ABS_MIN_MER)                                  */
-    int32_t max_mer;          /* MAX_MER, <= 32 on the device path of this ABI version        */
+    int32_t max_mer;          /* MAX_MER, <= 64; > 32 selects the 128-bit-word kernels         */
     double low_baseline;      /* LOW_BASELINE  (-L)                                           */
     double high_baseline;     /* HIGH_BASELINE (-H)                                           */
     int32_t slice_length;     /* SLICE_LENGTH (-s), long mode only                            */
@@ -126,9 +126,11 @@ int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_ro
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for
  * TREW_MODE_SEGMENT the (k_high, k_low, MAX_SEQ at k_high, MAX_SEQ at k_low)
  * that k_mer_check returns / reports through repeat_seq (kmer.cpp:2260-2262,
- * 2327).  Arrays of n_reads entries; any may be NULL. */
+ * 2327).  Arrays of n_reads entries; any may be NULL.  seq_* hold the low 64 bits of
+ * the word, seq_*_hi the high 64 bits (non-zero only for k > 32). */
 int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,
-                             uint64_t *seq_high, uint64_t *seq_low, uint64_t n_reads);
+                             uint64_t *seq_high, uint64_t *seq_low, uint64_t *seq_high_hi, uint64_t *seq_low_hi,
+                             uint64_t n_reads);
 /* Candidate-k masks of the prefilter for the last submit on `slot`: bit (k-1)
  * of cand[r*slots_per_read + s] is set when k survived for segment s of read r.
  * Diagnostic: used to test that the prefilter never drops a passing k. */

@@ -56,6 +56,16 @@ def test_cli_fixture_long(name):
     assert out == [">H:" + os.path.realpath(path), ">L:" + os.path.realpath(path), ">Putative_TRM", "NO_PUTATIVE_TRM,-1"]
 
 
+def test_cli_fixture_short_3_64():
+    # the recorded reference output of `short 3 64 test.fastq`, through the 128-bit kernels
+    path = os.path.join(GOLDEN, "test.fastq")
+    reads = read_fastq(path)
+    out = run("short", "3", "64", path)
+    assert out == expected([(path, O.run_short(O.OracleParams(min_mer=3, max_mer=64), reads))], 3)
+    rows = [r for r in out if r[0].isdigit()]
+    assert rows[0] == "3,TTA,157,105,0,-" and "3,TGA,4,+" in out and "3,TGG,3,+" in out
+
+
 def test_cli_fixture_short_3_32():
     # non-empty rows from the bundled fixture (k = 3 motifs), device limit MAX_MER <= 32
     path = os.path.join(GOLDEN, "test.fastq")

@@ -46,7 +46,7 @@ def _segment_parity(segs, min_mer, max_mer, low, high, flags):
         tabs = t.collect()
     bad = []
     for i, e in enumerate(exp):
-        got = (int(kh[i]), int(kl[i]), int(sh[i]), int(sl[i]))
+        got = (int(kh[i]), int(kl[i]), int(sh[i]), int(sl[i]))  # sh/sl: Python ints (hi << 64 | lo)
         want = (e["k_high"], e["k_low"], e["seq_high"], e["seq_low"])
         if got != want:
             bad.append((i, segs[i], got, want))
@@ -78,6 +78,70 @@ def test_segment_parity_long_segments():
 def test_segment_parity_other_params(mn, mx, low, high):
     segs = mixed_segments(13, 600, [30, 75, 100, 150])
     _segment_parity(segs, mn, mx, low, high, 0)
+
+
+KAT128 = [
+    "TGCAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA",
+    "TTAGGG",
+    "TTAGAGCCCACA",
+    "TTTTGCCCTCATCACACCCTCGCCTCCTTCGC",
+    "TTTTGCCCTCATCACACCCTCGCCTCCTTCGTGCTTGCCCCCACACTGACTGACGTGCAGTCTG",
+]
+
+
+@pytest.mark.parametrize("flags", [0, T.FLAG_NO_FILTER])
+@pytest.mark.parametrize("motif", KAT128)
+def test_k_mer_128_test_kat_on_gpu(motif, flags):
+    # test.cpp:216-258 restated against the HIP path (128-bit words)
+    r = T.k_mer_check((motif * 10).encode(), 5, 64, 0.5, 0.8, flags=flags)
+    assert len(r["hist_high"]) == 1
+    (k, w), c = next(iter(r["hist_high"].items()))
+    m = O.four_to_int(motif)
+    assert k == len(motif) == r["k_high"]
+    assert min(w, O.rot_seq(O.revcomp(w, k), k)) == min(m, O.rot_seq(O.revcomp(m, k), k))
+    assert c == len(motif) * 9 + 1
+    assert r == O.segment_check(O.OracleParams(max_mer=64), (motif * 10).encode())
+
+
+def _wide_segments(seed, count, lengths):
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(seed)
+    out = mixed_segments(seed, count // 2, lengths)
+    for i in range(count - count // 2):
+        n = rnd.choice(lengths)
+        unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(28, 64)))
+        out.append(mutate(periodic(unit, n, rnd.randint(0, 9)), rnd, p_sub=rnd.choice([0, 0.005, 0.02]), p_n=rnd.choice([0, 0, 0.004])).encode())
+    return out
+
+
+@pytest.mark.parametrize("mn,mx", [(5, 64), (3, 40), (33, 64), (5, 63)])
+def test_segment_parity_wide_words(mn, mx):
+    segs = _wide_segments(41, 700, [130, 150, 200, 256, 300, 640])
+    exp = _segment_parity(segs, mn, mx, 0.5, 0.8, 0)
+    assert sum(1 for e in exp if e["k_high"] > 32) > 50
+
+
+def test_short_parity_wide_words():
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(43)
+    reads = edge_reads(7)
+    for n in (150, 250, 300, 600, 1000):
+        for _ in range(40):
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(30, 64)))
+            reads.append(mutate(periodic(unit, n, rnd.randint(0, 9)), rnd, p_sub=rnd.choice([0, 0.01])).encode())
+    want = _short_parity(reads, max_mer=64)
+    assert any(k > 32 for t in want.values() for (k, _) in t)
+    # the bundled fixture at `3 64`: the five k = 3 rows
+    fx = read_fastq(os.path.join(GOLDEN, "test.fastq"))
+    w2 = _short_parity(fx, min_mer=3, max_mer=64)
+    h, lo = O.fold_tables(w2, 3)
+    assert "3,TTA,157,105,0,-" in O.format_sections("f", h, lo)
 
 
 def test_filter_is_sound():

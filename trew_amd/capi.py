@@ -96,7 +96,7 @@ def load():
     lib.trew_hip_collect.argtypes = [vp, i32, C.POINTER(Row), u64, C.POINTER(u64)]
     lib.trew_hip_reset_tables.argtypes = [vp]
     lib.trew_hip_add_rows.argtypes = [vp, C.POINTER(Row), u64]
-    lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, u64]
+    lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64]
     lib.trew_hip_filter_masks.argtypes = [vp, C.POINTER(Batch), vp, i32]
     lib.trew_hip_last_timing.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(u64)]
     lib.trew_pack_words.argtypes = [u64]
@@ -250,9 +250,15 @@ class TrewHip:
         kl = np.zeros(n_reads, dtype=np.int32)
         sh = np.zeros(n_reads, dtype=np.uint64)
         sl = np.zeros(n_reads, dtype=np.uint64)
+        shh = np.zeros(n_reads, dtype=np.uint64)
+        slh = np.zeros(n_reads, dtype=np.uint64)
         self._chk(self.lib.trew_hip_segment_results(self.ctx, slot, kh.ctypes.data, kl.ctypes.data, sh.ctypes.data,
-                                                    sl.ctypes.data, n_reads), "trew_hip_segment_results")
-        return kh, kl, sh, sl
+                                                    sl.ctypes.data, shh.ctypes.data, slh.ctypes.data, n_reads),
+                  "trew_hip_segment_results")
+        # words as Python ints (hi << 64 | lo)
+        seq_h = [(int(a) << 64) | int(b) for a, b in zip(shh, sh)]
+        seq_l = [(int(a) << 64) | int(b) for a, b in zip(slh, sl)]
+        return kh, kl, seq_h, seq_l
 
     def filter_masks(self, batch, slots_per_read):
         units = batch.n_reads // 2 if self.mode == MODE_PAIR else batch.n_reads

@@ -188,7 +188,6 @@ int main(int argc, char **argv) {
     if (!(0 < cfg.LOW_BASELINE && cfg.LOW_BASELINE <= 1) || !(0 < cfg.HIGH_BASELINE && cfg.HIGH_BASELINE <= 1)) return bad("Baseline must be in range 0 to 1.");
     if (cfg.LOW_BASELINE > cfg.HIGH_BASELINE) return bad("Low baseline must be smaller than high baseline.");
     if (cfg.NUM_THREAD < 2) return bad("You must use at least two threads.");
-    if (cfg.MAX_MER > 32) return bad("MAX_MER greater than 32 is not implemented on the HIP path yet.");
 
     std::vector<std::string> fastq_path_list;
     if (!IS_SHORT) {

@@ -47,6 +47,7 @@ struct trew_hip_ctx {
     trew_hip_params p;
     DevParams dp;
     DevTable table;
+    DevWide wide;  // host copy of *table.wide
     u64 table_slots = 0;
     std::vector<Slot> slots;
     std::string err;
@@ -119,7 +120,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     // same limits as the reference CLI (trew.cpp:175-228, 256-304) + this ABI version's device limits
     if (p.min_mer > p.max_mer) { g_init_error = "MIN_MER must not be greater than MAX_MER."; return -1; }
     if (p.min_mer < 3) { g_init_error = "MIN_MER must be greater than or equal to 3."; return -1; }
-    if (p.max_mer > 32) { g_init_error = "MAX_MER must be less than or equal to 32 on the HIP path (k in (32,64] is not implemented on device yet)."; return -1; }
+    if (p.max_mer > 64) { g_init_error = "MAX_MER must be less than or equal to 64."; return -1; }
     if (!(0 < p.low_baseline && p.low_baseline <= 1) || !(0 < p.high_baseline && p.high_baseline <= 1)) { g_init_error = "Baseline must be in range 0 to 1."; return -1; }
     if (p.low_baseline > p.high_baseline) { g_init_error = "Low baseline must be smaller than high baseline."; return -1; }
     if (p.mode < TREW_MODE_SHORT || p.mode > TREW_MODE_SEGMENT) { g_init_error = "unknown mode"; return -1; }
@@ -142,6 +143,8 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return -2; }
 
     trew_hip_ctx *ctx = new trew_hip_ctx();
+    memset(&ctx->table, 0, sizeof(ctx->table));
+    memset(&ctx->wide, 0, sizeof(ctx->wide));
     ctx->p = p;
     ctx->dp.min_mer = p.min_mer;
     ctx->dp.max_mer = p.max_mer;
@@ -167,6 +170,20 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     if ((e = hipMemset(ctx->table.keys, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->table.counts, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->table.overflow, 0, 4)) != hipSuccess) return bail("hipMemset", e);
+    // wide entries (k > 32) are rare: a quarter of the slots
+    ctx->wide.wide_log2_slots = std::max<u32>(10u, p.table_log2_slots - 2u);
+    {
+        const size_t wb = (size_t) 8 << ctx->wide.wide_log2_slots;
+        u64 **arr[4] = {&ctx->wide.wtag, &ctx->wide.wlo, &ctx->wide.whi, &ctx->wide.wcount};
+        for (auto a : arr) {
+            if ((e = hipMalloc((void **) a, wb)) != hipSuccess) return bail("hipMalloc(wide table)", e);
+            if ((e = hipMemset(*a, 0, wb)) != hipSuccess) return bail("hipMemset", e);
+        }
+        DevWide *dw = nullptr;
+        if ((e = hipMalloc((void **) &dw, sizeof(DevWide))) != hipSuccess) return bail("hipMalloc(wide descriptor)", e);
+        if ((e = hipMemcpy(dw, &ctx->wide, sizeof(DevWide), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+        ctx->table.wide = dw;
+    }
 
     ctx->slots.resize((size_t) p.n_slots);
     for (auto &s : ctx->slots) {
@@ -184,6 +201,8 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.seq_high, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.seq_low, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc((void **) &s.res.seq_high_hi, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
+            if ((e = hipMalloc((void **) &s.res.seq_low_hi, p.max_batch_reads * 8)) != hipSuccess) return bail("hipMalloc", e);
         }
         for (int i = 0; i < Slot::kRing; i++)
             for (int j = 0; j < 3; j++)
@@ -207,6 +226,8 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
         if (s.res.k_low) (void) hipFree(s.res.k_low);
         if (s.res.seq_high) (void) hipFree(s.res.seq_high);
         if (s.res.seq_low) (void) hipFree(s.res.seq_low);
+        if (s.res.seq_high_hi) (void) hipFree(s.res.seq_high_hi);
+        if (s.res.seq_low_hi) (void) hipFree(s.res.seq_low_hi);
         for (int i = 0; i < Slot::kRing; i++)
             for (int j = 0; j < 3; j++)
                 if (s.ev[i][j]) (void) hipEventDestroy(s.ev[i][j]);
@@ -215,6 +236,11 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->table.keys) (void) hipFree(ctx->table.keys);
     if (ctx->table.counts) (void) hipFree(ctx->table.counts);
     if (ctx->table.overflow) (void) hipFree(ctx->table.overflow);
+    if (ctx->wide.wtag) (void) hipFree(ctx->wide.wtag);
+    if (ctx->wide.wlo) (void) hipFree(ctx->wide.wlo);
+    if (ctx->wide.whi) (void) hipFree(ctx->wide.whi);
+    if (ctx->wide.wcount) (void) hipFree(ctx->wide.wcount);
+    if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
     delete ctx;
@@ -319,6 +345,8 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
         HIPCHK(ctx, hipMemsetAsync(s.res.k_low, 0, db.n_reads * 4, s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.res.seq_high, 0, db.n_reads * 8, s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.res.seq_low, 0, db.n_reads * 8, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.res.seq_high_hi, 0, db.n_reads * 8, s.stream));
+        HIPCHK(ctx, hipMemsetAsync(s.res.seq_low_hi, 0, db.n_reads * 8, s.stream));
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
     hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
@@ -372,11 +400,33 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     }
     hipStream_t st = ctx->slots[0].stream;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_collect_n, 0, 8, st));
-    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, table, ctx->d_collect_rows, dcap, ctx->d_collect_n));
+    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, ctx->wide.wide_log2_slots, table, ctx->d_collect_rows, dcap, ctx->d_collect_n));
     unsigned long long n = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_collect_n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (dcap && n) HIPCHK(ctx, hipMemcpy(rows, ctx->d_collect_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
+    if (dcap && n && n <= dcap) {
+        // the wide-entry protocol may leave one key in two slots (see table_add_wide): counts are sums, merge them
+        bool any_wide = false;
+        for (u64 i = 0; i < n && !any_wide; i++) any_wide = rows[i].k > 32;
+        if (any_wide) {
+            std::sort(rows, rows + n, [](const trew_hip_row &a, const trew_hip_row &b) {
+                if (a.table != b.table) return a.table < b.table;
+                if (a.k != b.k) return a.k < b.k;
+                if (a.word_hi != b.word_hi) return a.word_hi < b.word_hi;
+                return a.word_lo < b.word_lo;
+            });
+            u64 m = 0;
+            for (u64 i = 0; i < n; i++) {
+                if (m && rows[m - 1].table == rows[i].table && rows[m - 1].k == rows[i].k && rows[m - 1].word_hi == rows[i].word_hi &&
+                    rows[m - 1].word_lo == rows[i].word_lo)
+                    rows[m - 1].count += rows[i].count;
+                else
+                    rows[m++] = rows[i];
+            }
+            n = m;
+        }
+    }
     *n_rows = n;
     return 0;
 }
@@ -387,6 +437,11 @@ extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->table.keys, 0, ctx->table_slots * 8));
     HIPCHK(ctx, hipMemset(ctx->table.counts, 0, ctx->table_slots * 8));
     HIPCHK(ctx, hipMemset(ctx->table.overflow, 0, 4));
+    const size_t wb = (size_t) 8 << ctx->wide.wide_log2_slots;
+    HIPCHK(ctx, hipMemset(ctx->wide.wtag, 0, wb));
+    HIPCHK(ctx, hipMemset(ctx->wide.wlo, 0, wb));
+    HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
+    HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
     return 0;
 }
 
@@ -395,7 +450,7 @@ extern "C" int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, ui
     if (n_rows == 0) return 0;
     if (int rc = sync_all(ctx)) return rc;
     for (u64 i = 0; i < n_rows; i++)
-        if (rows[i].k < 1 || rows[i].k > 32 || rows[i].table < 0 || rows[i].table >= TREW_NUM_TABLES || rows[i].word_hi)
+        if (rows[i].k < 1 || rows[i].k > 64 || rows[i].table < 0 || rows[i].table >= TREW_NUM_TABLES || (rows[i].k <= 32 && rows[i].word_hi))
             return fail(ctx, "trew_hip_add_rows: row out of range");
     trew_hip_row *d = nullptr;
     HIPCHK(ctx, hipMalloc((void **) &d, n_rows * sizeof(trew_hip_row)));
@@ -408,7 +463,8 @@ extern "C" int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, ui
 }
 
 extern "C" int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,
-                                        uint64_t *seq_high, uint64_t *seq_low, uint64_t n_reads) {
+                                        uint64_t *seq_high, uint64_t *seq_low, uint64_t *seq_high_hi, uint64_t *seq_low_hi,
+                                        uint64_t n_reads) {
     if (!ctx) return -1;
     if (ctx->p.mode != TREW_MODE_SEGMENT) return fail(ctx, "segment results exist only in TREW_MODE_SEGMENT");
     if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
@@ -419,6 +475,8 @@ extern "C" int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_
     if (k_low) HIPCHK(ctx, hipMemcpy(k_low, s.res.k_low, n_reads * 4, hipMemcpyDeviceToHost));
     if (seq_high) HIPCHK(ctx, hipMemcpy(seq_high, s.res.seq_high, n_reads * 8, hipMemcpyDeviceToHost));
     if (seq_low) HIPCHK(ctx, hipMemcpy(seq_low, s.res.seq_low, n_reads * 8, hipMemcpyDeviceToHost));
+    if (seq_high_hi) HIPCHK(ctx, hipMemcpy(seq_high_hi, s.res.seq_high_hi, n_reads * 8, hipMemcpyDeviceToHost));
+    if (seq_low_hi) HIPCHK(ctx, hipMemcpy(seq_low_hi, s.res.seq_low_hi, n_reads * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

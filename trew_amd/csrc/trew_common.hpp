@@ -45,14 +45,24 @@ struct DevTable {
     u64 *counts;
     u32 log2_part_slots;  // slots per partition = 1 << log2_part_slots; 512 partitions
     u32 *overflow;
+    const struct DevWide *wide;  // device-resident descriptor of the wide-entry table (k > 32)
+};
+
+// wide entries (k in (32, 64], 128-bit words): tag / word halves / count per slot.  Kept behind a
+// pointer so that DevTable stays small enough to travel in registers.
+struct DevWide {
+    u64 *wtag, *wlo, *whi, *wcount;
+    u32 wide_log2_slots;
 };
 
 // per-read outputs of TREW_MODE_SEGMENT
 struct SegResults {
     int32_t *k_high;
     int32_t *k_low;
-    u64 *seq_high;
+    u64 *seq_high;     // low 64 bits of MAX_SEQ at k_high
     u64 *seq_low;
+    u64 *seq_high_hi;  // high 64 bits (k > 32)
+    u64 *seq_low_hi;
 };
 
 struct Segment {

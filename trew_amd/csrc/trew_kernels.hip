@@ -33,6 +33,8 @@
 
 namespace trew {
 
+typedef unsigned __int128 u128;  // 2k-bit words for k in (32, 64] (k_mer_check_128, kmer.cpp:2346-2547)
+
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) {
     return __builtin_amdgcn_alignbit(hi, lo, sh);  // ((hi:lo) >> (sh & 31)) & 0xffffffff
@@ -252,7 +254,7 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 #pragma unroll
         for (int j = 0; j < NW; j++) V[j] &= shr_word<NW, 0>(v1, j, (u32) t);
     }
-    for (int t = 32; t < gmin; t++) {
+    for (int t = 32; t < gmin && t < 64; t++) {
 #pragma unroll
         for (int j = 0; j < NW; j++) V[j] &= shr_word<NW, 1>(v1, j, (u32) t & 31u);
     }
@@ -260,11 +262,13 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
     const int g31 = gmax < 31 ? gmax : 31;
     if (NW <= 5) {
         FilterRange<NW, 0, NW>::run(P1, P2, P3, v1, V, gmin, g31, max_seg, lowf, clo, chi);
-        FilterRange<NW, 1, NW>::run(P1, P2, P3, v1, V, gmin > 32 ? gmin : 32, gmax, max_seg, lowf, clo, chi);
+        FilterRange<NW, 1, NW>::run(P1, P2, P3, v1, V, gmin > 32 ? gmin : 32, gmax < 63 ? gmax : 63, max_seg, lowf, clo, chi);
+        FilterRange<NW, 2, NW>::run(P1, P2, P3, v1, V, gmin > 64 ? gmin : 64, gmax, max_seg, lowf, clo, chi);
     } else {
         // long segments: all words every k (static trip counts would multiply the code size)
         for (int k = gmin; k <= g31; k++) filter_k<NW, 0, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
-        for (int k = gmin > 32 ? gmin : 32; k <= gmax; k++) filter_k<NW, 1, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
+        for (int k = gmin > 32 ? gmin : 32; k <= (gmax < 63 ? gmax : 63); k++) filter_k<NW, 1, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
+        for (int k = gmin > 64 ? gmin : 64; k <= gmax; k++) filter_k<NW, 2, NW>(P1, P2, P3, v1, V, k, lowf, clo, chi);
     }
     // only k inside the segment's own range can be candidates
     return ((((u64) chi) << 32) | clo) & all_k_mask(kmin, kmax);
@@ -404,6 +408,54 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
     atomicExch(T.overflow, 1u);
 }
 
+// Wide entries (k in (32, 64], 128-bit words).  Slot = {tag, word_lo, word_hi, count};
+// tag = bit 63 occupied | bit 62 ready | bits 61..59 table | bits 58..52 k | bits 51..0 hash(word).
+// A slot is claimed by one CAS on the tag, its word is published, then the ready bit is set.
+// Every access to a slot goes through device-scope atomic RMWs (the coherence point across the
+// 8 XCD L2s), so no fence protocol is needed.  If a racing inserter ever fails to recognise its
+// key it only creates a duplicate slot; trew_hip_collect merges duplicates (counts are sums).
+__device__ __forceinline__ u64 coherent_load(u64 *p) { return atomicOr((unsigned long long *) p, 0ull); }
+
+__attribute__((noinline)) __device__ void table_add_wide(DevTable T0, int table, int k, u64 lo, u64 hi, u64 cnt) {
+    if (T0.log2_part_slots == 0xffffffffu) return;  // TREW_FLAG_DEBUG_NO_EMIT
+    const DevWide T = *T0.wide;
+    const u64 READY = 1ull << 62;
+    const u64 h = hash64(lo ^ hash64(hi + (u64) k)) & ((1ull << 52) - 1ull);
+    const u64 base = (1ull << 63) | ((u64) table << 59) | ((u64) k << 52) | h;
+    const u32 S = 1u << T.wide_log2_slots, mask = S - 1u;
+    u32 idx = (u32) hash64(base) & mask;
+    for (u32 probe = 0; probe < S; probe++, idx = (idx + 1u) & mask) {
+        u64 t = coherent_load(&T.wtag[idx]);
+        if (t == 0) {
+            const u64 prev = atomicCAS((unsigned long long *) &T.wtag[idx], 0ull, base);
+            if (prev == 0) {
+                atomicExch((unsigned long long *) &T.wlo[idx], lo);
+                atomicExch((unsigned long long *) &T.whi[idx], hi);
+                __threadfence();
+                atomicOr((unsigned long long *) &T.wtag[idx], READY);
+                atomicAdd((unsigned long long *) &T.wcount[idx], cnt);
+                return;
+            }
+            t = prev;
+        }
+        if ((t & ~READY) == base) {
+            for (int spin = 0; !(t & READY) && spin < (1 << 20); spin++) t = coherent_load(&T.wtag[idx]);
+            if ((t & READY) && coherent_load(&T.wlo[idx]) == lo && coherent_load(&T.whi[idx]) == hi) {
+                atomicAdd((unsigned long long *) &T.wcount[idx], cnt);
+                return;
+            }
+        }
+    }
+    atomicExch(T0.overflow, 1u);
+}
+
+__device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 word, u64 cnt) {
+    if (k <= 32)
+        table_add(T, table, k, (u64) word, cnt);
+    else
+        table_add_wide(T, table, k, (u64) word, (u64) (word >> 64), cnt);
+}
+
 // ------------------------------------------------------------------ exact path
 // LDS working set of one wave, carved from dynamic LDS and sized by the longest
 // segment of the batch (cap bases, a multiple of 64): 2.6 KB for 150-bp reads, so
@@ -411,7 +463,6 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
 // The struct only carries the two sizes (it travels in SGPRs); every array is an
 // offset from the dynamic-LDS base so that accesses compile to ds_* instructions.
 //   seq   [cap/32+2] u64  2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
-//   canon [cap]      u64  per run (fast path) or per window (fallback)
 //   vmask [cap/64+2] u64  bit i: window i has no N
 //   emask [cap/64+2] u64  bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
 //   nmask [cap/32+2] u32  bit i = base i is not A/C/G/T or lies past the segment end
@@ -419,12 +470,17 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
 //   intent [32] u32  deferred histogram emissions of the pair driver
+//   canon [cap]  WT   per run (fast path) or per window (fallback); WT = u64 (k <= 32) or u128
 struct ExactSmem {
     u32 cap, rawwords;
 };
 
-__host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords) {
-    return (cap / 32 + 2) * 8 + cap * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 32 * 4 + 16;
+__host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
+    const u32 b = (cap / 32 + 2) * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
+    return (b + 15u) & ~15u;
+}
+__host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords, u32 wordbytes) {
+    return exact_lds_fixed(cap, rawwords) + cap * wordbytes + 16;
 }
 
 __device__ __forceinline__ unsigned char *lds0() {
@@ -432,14 +488,15 @@ __device__ __forceinline__ unsigned char *lds0() {
     return trew_lds;
 }
 __device__ __forceinline__ u64 *sm_seq(ExactSmem sm) { return (u64 *) lds0(); }
-__device__ __forceinline__ u64 *sm_canon(ExactSmem sm) { return sm_seq(sm) + (sm.cap / 32 + 2); }
-__device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_canon(sm) + sm.cap; }
+__device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_seq(sm) + (sm.cap / 32 + 2); }
 __device__ __forceinline__ u64 *sm_emask(ExactSmem sm) { return sm_vmask(sm) + (sm.cap / 64 + 2); }
 __device__ __forceinline__ u32 *sm_nmask(ExactSmem sm) { return (u32 *) (sm_emask(sm) + (sm.cap / 64 + 2)); }
 __device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm.cap / 32 + 2); }
 __device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 2 * sm.rawwords); }
 __device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
 __device__ __forceinline__ u32 *sm_intent(ExactSmem sm) { return (u32 *) (sm_start(sm) + sm.cap); }
+template <typename WT>
+__device__ __forceinline__ WT *sm_canon(ExactSmem sm) { return (WT *) (lds0() + exact_lds_fixed(sm.cap, sm.rawwords)); }
 
 __device__ __forceinline__ u64 spread32(u32 v) {
     u64 x = v;
@@ -485,10 +542,26 @@ __attribute__((noinline)) __device__ void load_segment(ExactSmem sm, const ReadR
     __syncthreads();
 }
 
-__device__ __forceinline__ u64 kmask(int k) { return k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull); }
 
-// get_rot_seq, kmer.cpp:1815-1823
-__device__ __forceinline__ u64 min_rotation(u64 w, int k) {
+template <typename WT>
+__device__ __forceinline__ WT kmask(int k) {
+    return 2 * k >= (int) (8 * sizeof(WT)) ? ~(WT) 0 : ((((WT) 1) << (2 * k)) - 1);
+}
+__device__ __forceinline__ u32 popc_word(u64 w) { return (u32) __popcll(w); }
+__device__ __forceinline__ u32 popc_word(u128 w) { return (u32) __popcll((u64) w) + (u32) __popcll((u64) (w >> 64)); }
+
+// value of lane `src` (wave-uniform index) for every lane
+__device__ __forceinline__ u64 readlane_word(u64 v, int src) {
+    const u32 lo = (u32) __builtin_amdgcn_readlane((int) (u32) v, src), hi = (u32) __builtin_amdgcn_readlane((int) (u32) (v >> 32), src);
+    return ((u64) hi << 32) | lo;
+}
+__device__ __forceinline__ u128 readlane_word(u128 v, int src) {
+    return ((u128) readlane_word((u64) (v >> 64), src) << 64) | readlane_word((u64) v, src);
+}
+
+// get_rot_seq / get_rot_seq_128, kmer.cpp:1815-1833
+template <typename WT>
+__device__ __forceinline__ WT min_rotation(WT w, int k) {
     const int sh = 2 * (k - 1);
     if (k <= 16) {  // wave-uniform: the 2k-bit word fits 32 bits
         u32 tmp = (u32) w, ans = (u32) w;
@@ -498,31 +571,50 @@ __device__ __forceinline__ u64 min_rotation(u64 w, int k) {
         }
         return ans;
     }
-    u64 tmp = w, ans = w;
+    if (sizeof(WT) > 8 && k <= 32) {  // fits 64 bits
+        u64 tmp = (u64) w, ans = (u64) w;
+        for (int i = 0; i < k - 1; i++) {
+            tmp = ((tmp & 3ull) << sh) | (tmp >> 2);
+            ans = tmp < ans ? tmp : ans;
+        }
+        return ans;
+    }
+    WT tmp = w, ans = w;
     for (int i = 0; i < k - 1; i++) {
-        tmp = ((tmp & 3ull) << sh) | (tmp >> 2);
+        tmp = ((tmp & 3) << sh) | (tmp >> 2);
         ans = tmp < ans ? tmp : ans;
     }
     return ans;
 }
-// reverse_complement_64(x) >> 2*(32-k), kmer.cpp:47-54 / 1987
-__device__ __forceinline__ u64 revcomp(u64 x, int k) {
+// reverse the 32 2-bit groups of a 64-bit word and complement them
+__device__ __forceinline__ u64 revcomp_groups64(u64 x) {
     x = (x >> 32) | (x << 32);
     x = ((x >> 16) & 0x0000ffff0000ffffull) | ((x & 0x0000ffff0000ffffull) << 16);
     x = ((x >> 8) & 0x00ff00ff00ff00ffull) | ((x & 0x00ff00ff00ff00ffull) << 8);
     x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
     x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    return (~x) >> (2 * (32 - k));
+    return ~x;
 }
-// get_repeat_check, kmer.cpp:1835-1850: the word uses a single base
-__device__ __forceinline__ bool is_homopolymer(u64 w, int k) {
-    return w == ((w & 3ull) * (0x5555555555555555ull & kmask(k)));
+// reverse_complement_64(x) >> 2*(32-k), kmer.cpp:47-54 / 1987
+__device__ __forceinline__ u64 revcomp(u64 x, int k) { return revcomp_groups64(x) >> (2 * (32 - k)); }
+// reverse_complement_128(x) >> 2*(64-k), kmer.cpp:62-70
+__device__ __forceinline__ u128 revcomp(u128 x, int k) {
+    const u128 r = ((u128) revcomp_groups64((u64) x) << 64) | revcomp_groups64((u64) (x >> 64));
+    return r >> (2 * (64 - k));
+}
+// get_repeat_check, kmer.cpp:1835-1867: the word uses a single base
+template <typename WT>
+__device__ __forceinline__ bool is_homopolymer(WT w, int k) {
+    WT fives = (WT) 0x5555555555555555ull;
+    if (sizeof(WT) > 8) fives |= fives << 64 % (8 * sizeof(WT));
+    return w == ((w & 3) * (fives & kmask<WT>(k)));
 }
 
+template <typename WT>
 struct KStat {
     u32 count;   // K_MER_DATA_COUNT
     u32 maxc;    // K_MER_DATA_MAX
-    u64 maxseq;  // K_MER_DATA_MAX_SEQ
+    WT maxseq;   // K_MER_DATA_MAX_SEQ
     u32 n_items; // entries of canon[]/cnt[] left in LDS for emit_k
     bool pruned; // the bucket bound proved MAX/COUNT < need: maxc/maxseq were not computed
 };
@@ -530,22 +622,37 @@ struct KStat {
 __device__ __forceinline__ u32 base_at(ExactSmem sm, u32 p) {
     return (u32) (sm_seq(sm)[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
 }
-__device__ __forceinline__ u64 window_word(ExactSmem sm, u32 i, int k) {
+template <typename WT>
+__device__ __forceinline__ WT window_word(ExactSmem sm, u32 i, int k);
+template <>
+__device__ __forceinline__ u64 window_word<u64>(ExactSmem sm, u32 i, int k) {
     const u32 wi = i >> 5, sh = 2u * (i & 31u);
     const u64 a = sm_seq(sm)[wi], b = sm_seq(sm)[wi + 1];
     const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
     return x >> (64 - 2 * k);
 }
-__device__ __forceinline__ bool window_valid(ExactSmem sm, u32 i, int k) {
+template <>
+__device__ __forceinline__ u128 window_word<u128>(ExactSmem sm, u32 i, int k) {
+    const u32 wi = i >> 5, sh = 2u * (i & 31u);
+    const u64 a = sm_seq(sm)[wi], b = sm_seq(sm)[wi + 1], c = sm_seq(sm)[wi + 2];
+    const u128 ab = ((u128) a << 64) | b;
+    const u128 x = sh ? ((ab << sh) | (u128) (c >> (64u - sh))) : ab;
+    return x >> (128 - 2 * k);
+}
+__device__ __forceinline__ bool window_valid(ExactSmem sm, u32 i, int k) {  // k <= 64
     const u32 wi = i >> 5, bi = i & 31u;
-    const u64 nmw = (((u64) sm_nmask(sm)[wi + 1] << 32) | sm_nmask(sm)[wi]) >> bi;
-    return (nmw & ((1ull << k) - 1ull)) == 0;  // no N inside the window (kmer.cpp:2190)
+    const u64 lo = ((u64) sm_nmask(sm)[wi + 1] << 32) | sm_nmask(sm)[wi];
+    const u64 hi = sm_nmask(sm)[wi + 2];
+    const u64 nmw = bi ? ((lo >> bi) | (hi << (64u - bi))) : lo;
+    const u64 km = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    return (nmw & km) == 0;  // no N inside the window (kmer.cpp:2190)
 }
 
 // wave argmax over per-lane (key, seq): largest class, ties to the class whose
 // last window is earliest = the first to reach the maximum in scan order
 // (strict '<' at kmer.cpp:2202).  key = (class size << 16) | (0xffff - last window)
-__device__ __forceinline__ void wave_best(u32 best, u64 best_seq, KStat &st) {
+template <typename WT>
+__device__ __forceinline__ void wave_best(u32 best, WT best_seq, KStat<WT> &st) {
     u32 m = best;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (u32) __shfl_xor((int) m, off));
@@ -553,30 +660,31 @@ __device__ __forceinline__ void wave_best(u32 best, u64 best_seq, KStat &st) {
     if (who) {
         const int src = __ffsll((long long) who) - 1;
         st.maxc = m >> 16;
-        st.maxseq = ((u64) (u32) __shfl((int) (best_seq >> 32), src) << 32) | (u32) __shfl((int) (u32) best_seq, src);
+        st.maxseq = readlane_word(best_seq, src);
     }
 }
 
 // Fallback for segments with more than 64 runs: one item per window, class sizes
 // by an all-pairs LDS-broadcast compare.  vmask[] must hold the valid-window bits.
-__attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, int k, KStat &st) {
+template <typename WT>
+__attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, int k, KStat<WT> &st) {
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
         if (i < W) {
             const bool valid = (sm_vmask(sm)[r] >> lane) & 1ull;
-            sm_canon(sm)[i] = valid ? min_rotation(window_word(sm, (u32) i, k), k) : 0ull;
+            sm_canon<WT>(sm)[i] = valid ? min_rotation<WT>(window_word<WT>(sm, (u32) i, k), k) : (WT) 0;
             sm_cnt(sm)[i] = 0;
         }
     }
     __syncthreads();
     u32 best = 0;
-    u64 best_seq = 0;
+    WT best_seq = 0;
     for (int r = 0; r < rounds; r++) {
         const int i = r * 64 + (int) lane;
         const bool mine = i < W && ((sm_vmask(sm)[r] >> lane) & 1ull);
-        const u64 my = mine ? sm_canon(sm)[i] : 0;
+        const WT my = mine ? sm_canon<WT>(sm)[i] : (WT) 0;
         u32 c = 0, last = 0;
         bool first = true;
         for (int jr = 0; jr < rounds; jr++) {
@@ -585,7 +693,7 @@ __attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, in
                 const int jb = __ffsll((long long) vm) - 1;
                 vm &= vm - 1;
                 const int j = jr * 64 + jb;
-                const bool eq = sm_canon(sm)[j] == my;  // LDS broadcast read
+                const bool eq = sm_canon<WT>(sm)[j] == my;  // LDS broadcast read
                 c += eq ? 1u : 0u;
                 last = eq ? (u32) j : last;
                 first = first && !(eq && j < i);
@@ -600,11 +708,12 @@ __attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, in
             }
         }
     }
-    wave_best(best, best_seq, st);
+    wave_best<WT>(best, best_seq, st);
     st.n_items = (u32) W;
 }
 
-__device__ void eval_runs(ExactSmem sm, int W, int k, KStat &st);
+template <typename WT>
+__device__ void eval_runs(ExactSmem sm, int W, int k, KStat<WT> &st);
 
 // One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
 // 1936-1967) on the segment staged in sm.  Lemma A: two
@@ -619,8 +728,9 @@ __device__ void eval_runs(ExactSmem sm, int W, int k, KStat &st);
 // bounds MAX from above; if even that bound gives a frequency below `need`
 // (the smallest threshold this k still has to reach in decide()), the k cannot
 // be accepted and the per-run canonicalisation is skipped (st.pruned).
-__attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, double need) {
-    KStat st;
+template <typename WT>
+__attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k, double need) {
+    KStat<WT> st;
     st.count = 0;
     st.maxc = 0;
     st.maxseq = 0;
@@ -630,7 +740,9 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
     if (W <= 0) return st;
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
-    const u64 m5 = 0x5555555555555555ull & kmask(k);
+    WT m5 = (WT) 0x5555555555555555ull;
+    if (sizeof(WT) > 8) m5 |= m5 << 64 % (8 * sizeof(WT));
+    m5 &= kmask<WT>(k);
     u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
     __syncthreads();  // previous users of the LDS arrays are done
     for (int r = 0; r < rounds; r++) {
@@ -638,11 +750,11 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
         bool valid = false, eq = false, p1 = false, p2 = false, p3 = false;
         if ((int) i < W) {
             valid = window_valid(sm, i, k);
-            const u64 w = window_word(sm, i, k);
+            const WT w = window_word<WT>(sm, i, k);
             eq = (u32) (w >> (2 * k - 2)) == base_at(sm, i + (u32) k);
-            p1 = __popcll(w & m5) & 1;
-            p2 = __popcll((w >> 1) & m5) & 1;
-            p3 = __popcll(w & (w >> 1) & m5) & 1;
+            p1 = popc_word(w & m5) & 1;
+            p2 = popc_word((w >> 1) & m5) & 1;
+            p3 = popc_word(w & (w >> 1) & m5) & 1;
         }
         const u64 bv = __ballot(valid), be = __ballot(eq);
         if (lane == 0) {
@@ -681,12 +793,13 @@ __attribute__((noinline)) __device__ KStat eval_k(ExactSmem sm, int L, int k, do
             return st;
         }
     }
-    eval_runs(sm, W, k, st);
+    eval_runs<WT>(sm, W, k, st);
     return st;
 }
 
 // Second half of eval_k: vmask[] / emask[] (+ one zero word) are in LDS, visible to the wave.
-__attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, KStat &st) {
+template <typename WT>
+__attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, KStat<WT> &st) {
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
@@ -704,12 +817,12 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
     st.count = count;
     __syncthreads();
     if (R > 64) {
-        eval_k_windows(sm, W, k, st);
+        eval_k_windows<WT>(sm, W, k, st);
         __syncthreads();
         return;
     }
     // one lane per run
-    u64 canon = ~0ull;
+    WT canon = ~(WT) 0;
     u32 len = 0, s = 0;
     if (lane < R) {
         s = sm_start(sm)[lane];
@@ -727,18 +840,16 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
             j += ones;
             if (j >= (u32) W) break;
         }
-        canon = min_rotation(window_word(sm, s, k), k);
+        canon = min_rotation<WT>(window_word<WT>(sm, s, k), k);
     }
     const u32 end = s + len - 1;
     u32 tot = 0, last = 0;
     bool first = true;
-    const u32 clo = (u32) canon, chi = (u32) (canon >> 32);
     for (u32 rp = 0; rp < R; rp++) {  // wave-uniform: broadcast run rp to every lane, no LDS round trip
-        const u32 olo = (u32) __builtin_amdgcn_readlane((int) clo, (int) rp);
-        const u32 ohi = (u32) __builtin_amdgcn_readlane((int) chi, (int) rp);
+        const WT other = readlane_word(canon, (int) rp);
         const u32 olen = (u32) __builtin_amdgcn_readlane((int) len, (int) rp);
         const u32 oend = (u32) __builtin_amdgcn_readlane((int) end, (int) rp);
-        const bool eq = olo == clo && ohi == chi;
+        const bool eq = other == canon;
         tot += eq ? olen : 0u;
         last = eq ? oend : last;
         first = first && !(eq && rp < lane);
@@ -746,10 +857,10 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
     u32 key = 0;
     if (lane < R) {
         key = (tot << 16) | (0xffffu - last);
-        sm_canon(sm)[lane] = canon;
+        sm_canon<WT>(sm)[lane] = canon;
         sm_cnt(sm)[lane] = first ? (unsigned short) tot : (unsigned short) 0;
     }
-    wave_best(key, canon, st);
+    wave_best<WT>(key, canon, st);
     st.n_items = R;
     __syncthreads();
 }
@@ -757,14 +868,15 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
 // add every class of the k just evaluated to the tables in table_mask (bit t).
 // strand_canon: key = MIN(w, rot(rc(w))) (k_mer_target, kmer.cpp:1979-1988) else the
 // rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
+template <typename WT>
 __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
     const u32 lane = lane_id();
     for (u32 i = lane; i < n_items; i += 64) {
         const u32 c = sm_cnt(sm)[i];
         if (c) {
-            u64 w = sm_canon(sm)[i];
+            WT w = sm_canon<WT>(sm)[i];
             if (strand_canon) {
-                const u64 rc = min_rotation(revcomp(w, k), k);
+                const WT rc = min_rotation<WT>(revcomp(w, k), k);
                 w = rc < w ? rc : w;
             }
             for (u32 tm = table_mask; tm; tm &= tm - 1) table_add(T, __ffs((int) tm) - 1, k, w, c);
@@ -891,9 +1003,10 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
     return __hiloint2double(hi, lo);
 }
 
+template <typename WT>
 struct Decision {
     int kh, kl;   // target_k_high / target_k_low
-    u64 sh, sl;   // MAX_SEQ at those k (repeat_seq, kmer.cpp:2260-2262)
+    WT sh, sl;    // MAX_SEQ at those k (repeat_seq, kmer.cpp:2260-2262)
 };
 
 // bits j-1 for every multiple j <= 64 of k
@@ -915,11 +1028,11 @@ __device__ __forceinline__ bool divides_any(int k, u64 accepted) {
 // selection loops of k_mer_check, kmer.cpp:2221-2258, run online over ascending
 // candidate k (non-candidates have frequency < LOW and can never be accepted)
 // M: per-lane knowledge of lane_bounds() (lane l <-> k = MIN_MER + l); ignored when NW == 0
-template <int NW>
-__device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, const LaneMasks<(NW > 0 ? NW : 1)> &M) {
+template <int NW, typename WT>
+__device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, const LaneMasks<(NW > 0 ? NW : 1)> &M) {
     constexpr bool HAVE_UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    Decision d;
+    Decision<WT> d;
     d.kh = d.kl = 0;
     d.sh = d.sl = 0;
     double tf_low = 0.0, tf_high = 0.0;
@@ -935,7 +1048,7 @@ __device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, in
         const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
         const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
-        KStat st;
+        KStat<WT> st;
         if (HAVE_UB) {
             const int src = k - P.min_mer;
             // MAX <= maxbucket and IEEE division is monotone in the numerator: f <= bound < need
@@ -966,14 +1079,14 @@ __device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, in
                     em[nq] = 0;
                 }
                 __syncthreads();
-                eval_runs(sm, W, k, st);
+                eval_runs<WT>(sm, W, k, st);
             }
         } else {
-            st = eval_k(sm, L, k, need);
+            st = eval_k<WT>(sm, L, k, need);
         }
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
-        if (is_homopolymer(st.maxseq, k)) continue;
+        if (is_homopolymer<WT>(st.maxseq, k)) continue;
         if (lo_open && f >= thr_lo) {
             d.kl = k;
             tf_low = f;
@@ -991,25 +1104,27 @@ __device__ Decision decide(ExactSmem sm, const DevParams &P, int L, int kmin, in
 }
 
 // record the histogram of segment (already staged) at k into tables
+template <typename WT>
 __device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
     if (k <= 0 || table_mask == 0) return;
-    const KStat st = eval_k(sm, L, k, 0.0);
-    emit_k(sm, T, st.n_items, k, table_mask, strand_canon);
+    const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
+    emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
 // k_mer_target, kmer.cpp:1894-2017, on the staged whole read
+template <typename WT>
 __device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
-    const KStat st = eval_k(sm, L, k, 0.0);
+    const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
     if (st.count == 0) return;
-    const double f = is_homopolymer(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
+    const double f = is_homopolymer<WT>(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
     u32 tm = 0;
     if (want_high && f >= P.high) tm |= 1u << TREW_TABLE_BOTH_HIGH;
     if (want_low && f >= P.low) tm |= 1u << TREW_TABLE_BOTH_LOW;
-    if (tm) emit_k(sm, T, st.n_items, k, tm, true);
+    if (tm) emit_k<WT>(sm, T, st.n_items, k, tm, true);
 }
 
 // buffer_task, kmer.cpp:111-173
-template <int NW>
+template <int NW, typename WT>
 __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
@@ -1018,7 +1133,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sW = get_segment(TREW_MODE_SHORT, 2, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
-    Decision left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
+    Decision<WT> left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
     if (sL.valid) {
         load_segment(sm, rd, sL.start, sL.len);
         LaneMasks<NWB> mL, mR;
@@ -1026,9 +1141,9 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
             lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
             lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
         }
-        left = decide<NW>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL);
+        left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL);
         load_segment(sm, rd, sR.start, sR.len);
-        right = decide<NW>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR);
+        right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
@@ -1039,10 +1154,10 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
             const bool rec_h = right.kh > 0 && (!left_found || (left.kh == 0));
             const bool rec_l = right.kl > 0 && (!left_found || (left.kl == 0));
             if (rec_h && rec_l && right.kh == right.kl) {
-                record(sm, T, (int) sR.len, right.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
+                record<WT>(sm, T, (int) sR.len, right.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
             } else {
-                if (rec_h) record(sm, T, (int) sR.len, right.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
-                if (rec_l) record(sm, T, (int) sR.len, right.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+                if (rec_h) record<WT>(sm, T, (int) sR.len, right.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
+                if (rec_l) record<WT>(sm, T, (int) sR.len, right.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
             }
         }
         if (left_found) {
@@ -1051,19 +1166,19 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
             if (rec_h || rec_l) {
                 load_segment(sm, rd, sL.start, sL.len);
                 if (rec_h && rec_l && left.kh == left.kl) {
-                    record(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
+                    record<WT>(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
                 } else {
-                    if (rec_h) record(sm, T, (int) sL.len, left.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
-                    if (rec_l) record(sm, T, (int) sL.len, left.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
+                    if (rec_h) record<WT>(sm, T, (int) sL.len, left.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
+                    if (rec_l) record<WT>(sm, T, (int) sL.len, left.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
                 }
             }
             if (tgt_h || tgt_l) {
                 load_segment(sm, rd, 0, (u32) n);
                 if (tgt_h && tgt_l && left.kh == left.kl) {
-                    target(sm, P, T, n, left.kh, true, true);
+                    target<WT>(sm, P, T, n, left.kh, true, true);
                 } else {
-                    if (tgt_h) target(sm, P, T, n, left.kh, true, false);
-                    if (tgt_l) target(sm, P, T, n, left.kl, false, true);
+                    if (tgt_h) target<WT>(sm, P, T, n, left.kh, true, false);
+                    if (tgt_l) target<WT>(sm, P, T, n, left.kl, false, true);
                 }
             }
         }
@@ -1074,19 +1189,19 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
         load_segment(sm, rd, 0, (u32) n);
         LaneMasks<NWB> mW;
         if (UB) lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer, mW);
-        const Decision w = decide<NW>(sm, P, n, sW.kmin, sW.kmax, ~0ull, mW);
+        const Decision<WT> w = decide<NW, WT>(sm, P, n, sW.kmin, sW.kmax, ~0ull, mW);
         const bool rec_h = hh && w.kh > 0, rec_l = lh && w.kl > 0;
         if (rec_h && rec_l && w.kh == w.kl) {
-            record(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
+            record<WT>(sm, T, n, w.kh, (1u << TREW_TABLE_BOTH_HIGH) | (1u << TREW_TABLE_BOTH_LOW), false);
         } else {
-            if (rec_h) record(sm, T, n, w.kh, 1u << TREW_TABLE_BOTH_HIGH, false);
-            if (rec_l) record(sm, T, n, w.kl, 1u << TREW_TABLE_BOTH_LOW, false);
+            if (rec_h) record<WT>(sm, T, n, w.kh, 1u << TREW_TABLE_BOTH_HIGH, false);
+            if (rec_l) record<WT>(sm, T, n, w.kl, 1u << TREW_TABLE_BOTH_LOW, false);
         }
     }
 }
 
 // TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
-template <int NW>
+template <int NW, typename WT>
 __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit,
                             const SegResults &R) {
     constexpr bool UB = NW > 0;
@@ -1097,18 +1212,22 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B,
     load_segment(sm, rd, 0, s.len);
     LaneMasks<NWB> m;
     if (UB) lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer, m);
-    const Decision d = decide<NW>(sm, P, (int) s.len, s.kmin, s.kmax, ~0ull, m);
+    const Decision<WT> d = decide<NW, WT>(sm, P, (int) s.len, s.kmin, s.kmax, ~0ull, m);
     if (d.kh > 0 && d.kh == d.kl) {
-        record(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
+        record<WT>(sm, T, (int) s.len, d.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
     } else {
-        record(sm, T, (int) s.len, d.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
-        record(sm, T, (int) s.len, d.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
+        record<WT>(sm, T, (int) s.len, d.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
+        record<WT>(sm, T, (int) s.len, d.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
     }
     if (lane_id() == 0 && R.k_high) {
         R.k_high[unit] = d.kh;
         R.k_low[unit] = d.kl;
-        R.seq_high[unit] = d.sh;
-        R.seq_low[unit] = d.sl;
+        R.seq_high[unit] = (u64) d.sh;
+        R.seq_low[unit] = (u64) d.sl;
+        if (R.seq_high_hi) {
+            R.seq_high_hi[unit] = sizeof(WT) > 8 ? (u64) (d.sh >> (8 * sizeof(WT) - 64)) : 0ull;
+            R.seq_low_hi[unit] = sizeof(WT) > 8 ? (u64) (d.sl >> (8 * sizeof(WT) - 64)) : 0ull;
+        }
     }
 }
 
@@ -1124,7 +1243,7 @@ __device__ __forceinline__ void long_slice(int t, int mid, int bonus, int SL, u3
 // whose destination (both, strand-canonical / forward) is only known when the walk ends, so
 // it runs twice: pass 1 decides, pass 2 re-decides the recorded slices and emits.  The
 // backward walk records straight into result.backward (kmer.cpp:840).
-template <int NW>
+template <int NW, typename WT>
 __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
@@ -1141,14 +1260,14 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         load_segment(sm, rd, st, sl);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(rd, st, (int) sl, P.min_mer, P.max_mer, m);
-        return decide<NW>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m);
+        return decide<NW, WT>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m);
     };
     auto slice_len = [&](int t) { return (int) (SL + (t == mid ? bonus : 0)); };
     // pass 1: forward chain (kmer.cpp:797-817)
     int si[2] = {1, 1}, kmer[2] = {0, 0}, last_rec[2] = {0, 0};
     bool rend[2] = {false, false};
     for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {
-        const Decision d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+        const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
         const int tk[2] = {d.kh, d.kl};
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -1169,13 +1288,13 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const u32 th = canon_h ? TREW_TABLE_BOTH_HIGH : TREW_TABLE_FORWARD_HIGH;
         const u32 tl = canon_l ? TREW_TABLE_BOTH_LOW : TREW_TABLE_FORWARD_LOW;
         for (int ti = 1; ti <= upto; ti++) {
-            const Decision d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+            const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
             const bool rh = ti <= last_rec[0] && d.kh > 0, rl = ti <= last_rec[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl && canon_h == canon_l) {
-                record(sm, T, slice_len(ti), d.kh, (1u << th) | (1u << tl), canon_h);
+                record<WT>(sm, T, slice_len(ti), d.kh, (1u << th) | (1u << tl), canon_h);
             } else {
-                if (rh) record(sm, T, slice_len(ti), d.kh, 1u << th, canon_h);
-                if (rl) record(sm, T, slice_len(ti), d.kl, 1u << tl, canon_l);
+                if (rh) record<WT>(sm, T, slice_len(ti), d.kh, 1u << th, canon_h);
+                if (rl) record<WT>(sm, T, slice_len(ti), d.kl, 1u << tl, canon_l);
             }
         }
     }
@@ -1185,13 +1304,13 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         kmer[0] = kmer[1] = 0;
         rend[0] = rend[1] = false;
         for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
-            const Decision d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk));
+            const Decision<WT> d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk));
             const bool rh = !rend[0] && d.kh > 0, rl = !rend[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl) {
-                record(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
+                record<WT>(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
             } else {
-                if (rh) record(sm, T, slice_len(tj), d.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
-                if (rl) record(sm, T, slice_len(tj), d.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+                if (rh) record<WT>(sm, T, slice_len(tj), d.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
+                if (rl) record<WT>(sm, T, slice_len(tj), d.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
             }
             const int tk[2] = {d.kh, d.kl};
 #pragma unroll
@@ -1217,15 +1336,16 @@ __device__ __forceinline__ u32 pack_intent(int slot, int k, int b, int temp) {
 __device__ __forceinline__ u32 dest(int temp, int b, int table) { return (1u << table) << (8 * (2 * temp + b)); }
 
 // get_dir_seq, kmer.cpp:307-313
-__device__ __forceinline__ u64 dir_seq(int i, int k, u64 seq, bool is_for) {
+template <typename WT>
+__device__ __forceinline__ WT dir_seq(int i, int k, WT seq, bool is_for) {
     if ((i <= 2) == is_for) return seq;
-    return min_rotation(revcomp(seq, k), k);
+    return min_rotation<WT>(revcomp(seq, k), k);
 }
 
 // buffer_task_pair, kmer.cpp:322-507, with the 128-bit twin's clear of temp_result_left after
 // the whole-read block (kmer.cpp:722-723; SURVEY G1 -- the one documented divergence from the
 // 64-bit branch, whose stale map makes results depend on thread scheduling).
-template <int NW>
+template <int NW, typename WT>
 __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit_in) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
@@ -1245,7 +1365,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         load_segment(sm, r, sg.start, sg.len);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
-        return decide<NW>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        return decide<NW, WT>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
         if (k > 0 && n_int < 32) {
@@ -1278,29 +1398,29 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             if (mp | mc) {
                 const Segment sg = seg_of(slot);
                 load_segment(sm, sg.mate ? r1 : r0, sg.start, sg.len);
-                const KStat st = eval_k(sm, (int) sg.len, k, 0.0);
-                if (mp) emit_k(sm, T, st.n_items, k, mp, false);
-                if (mc) emit_k(sm, T, st.n_items, k, mc, true);
+                const KStat<WT> st = eval_k<WT>(sm, (int) sg.len, k, 0.0);
+                if (mp) emit_k<WT>(sm, T, st.n_items, k, mp, false);
+                if (mc) emit_k<WT>(sm, T, st.n_items, k, mc, true);
             }
         }
         if (clear) n_int = 0;
         __syncthreads();
     };
     int lef_k[2] = {0, 0}, kmer[2] = {0, 0};
-    u64 kseq[2] = {0, 0};
+    WT kseq[2] = {0, 0};
     if (4 * P.min_mer <= n) {
         // fragment order R1-left, R1-right, R2-right, R2-left = slots 0..3 (kmer.cpp:338-340)
         const int snum = 4;
         int si[2] = {1, 1};
         bool rend[2] = {false, false};
         for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {  // kmer.cpp:347-374
-            const Decision d = seg_decide(ti - 1);
+            const Decision<WT> d = seg_decide(ti - 1);
             const int tk[2] = {d.kh, d.kl};
-            const u64 ts[2] = {d.sh, d.sl};
+            const WT ts[2] = {d.sh, d.sl};
 #pragma unroll
             for (int b = 0; b < 2; b++) {
                 if (!rend[b]) add_intent(ti - 1, tk[b], b, ti <= 2 ? 0 : 1);
-                if (!rend[b] && tk[b] > 0 && ((kmer[b] == tk[b] && kseq[b] == dir_seq(ti, tk[b], ts[b], true)) || ti == 1)) {
+                if (!rend[b] && tk[b] > 0 && ((kmer[b] == tk[b] && kseq[b] == dir_seq<WT>(ti, tk[b], ts[b], true)) || ti == 1)) {
                     si[b] += 1;
                     kmer[b] = tk[b];
                     if (ti == 1) kseq[b] = ts[b];
@@ -1331,14 +1451,14 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             kmer[0] = kmer[1] = 0;
             rend[0] = rend[1] = false;
             for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
-                const Decision d = seg_decide(tj - 1);
+                const Decision<WT> d = seg_decide(tj - 1);
                 const int tk[2] = {d.kh, d.kl};
-                const u64 ts[2] = {d.sh, d.sl};
+                const WT ts[2] = {d.sh, d.sl};
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
                     if (!rend[b]) add_intent(tj - 1, tk[b], b, tj <= 2 ? 1 : 0);
                     if (sj[b] >= si[b] && !rend[b] && tk[b] > 0 &&
-                        ((kmer[b] == tk[b] && kseq[b] == dir_seq(tj, tk[b], ts[b], false)) || tj == snum)) {
+                        ((kmer[b] == tk[b] && kseq[b] == dir_seq<WT>(tj, tk[b], ts[b], false)) || tj == snum)) {
                         sj[b] -= 1;
                         kmer[b] = tk[b];
                         if (tj == snum) kseq[b] = ts[b];
@@ -1356,7 +1476,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
     }
     if (4 * P.max_mer > n) {  // whole-read block, kmer.cpp:467-505
-        Decision lt = {0, 0, 0, 0}, rt = {0, 0, 0, 0};
+        Decision<WT> lt = {0, 0, 0, 0}, rt = {0, 0, 0, 0};
         if (lef_k[0] == 0 || lef_k[1] == 0) {
             lt = seg_decide(4);
             if (lef_k[0] == 0) add_intent(4, lt.kh, 0, 0);
@@ -1369,9 +1489,9 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
         const u32 plain = dest(0, 0, TREW_TABLE_FORWARD_HIGH) | dest(0, 1, TREW_TABLE_FORWARD_LOW);
         u32 canon = 0;
-        if (lef_k[0] == 0 && kmer[0] == 0 && lt.kh == rt.kh && lt.kh > 0 && lt.sh == min_rotation(revcomp(rt.sh, rt.kh), rt.kh))
+        if (lef_k[0] == 0 && kmer[0] == 0 && lt.kh == rt.kh && lt.kh > 0 && lt.sh == min_rotation<WT>(revcomp(rt.sh, rt.kh), rt.kh))
             canon |= dest(0, 0, TREW_TABLE_BOTH_HIGH);
-        if (lef_k[1] == 0 && kmer[1] == 0 && lt.kl == rt.kl && lt.kl > 0 && lt.sl == min_rotation(revcomp(rt.sl, rt.kl), rt.kl))
+        if (lef_k[1] == 0 && kmer[1] == 0 && lt.kl == rt.kl && lt.kl > 0 && lt.sl == min_rotation<WT>(revcomp(rt.sl, rt.kl), rt.kl))
             canon |= dest(0, 1, TREW_TABLE_BOTH_LOW);
         flush(plain, canon, 3u, true);
     }
@@ -1380,7 +1500,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
 
 // NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
 // NW == 0: long segments, pruning happens inside eval_k instead.
-template <int NW, int MODE>
+template <int NW, int MODE, typename WT>
 __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevTable T, const u32 *wl,
                                                    u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
     ExactSmem sm;
@@ -1410,13 +1530,13 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
         const u32 it = wl[w];
         // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
         if (MODE == TREW_MODE_SHORT)
-            run_short<NW>(sm, P, B, T, it);
+            run_short<NW, WT>(sm, P, B, T, it);
         else if (MODE == TREW_MODE_SEGMENT)
-            run_segment<NW>(sm, P, B, T, it, R);
+            run_segment<NW, WT>(sm, P, B, T, it, R);
         else if (MODE == TREW_MODE_LONG)
-            run_long<NW>(sm, P, B, T, it);
+            run_long<NW, WT>(sm, P, B, T, it);
         else
-            run_pair<NW>(sm, P, B, T, it);
+            run_pair<NW, WT>(sm, P, B, T, it);
         __syncthreads();
         }
         }
@@ -1426,13 +1546,32 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
 // ------------------------------------------------------------------ table maintenance
 __global__ void table_add_rows_kernel(DevTable T, const trew_hip_row *rows, u64 n) {
     const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) table_add(T, rows[i].table, rows[i].k, rows[i].word_lo, rows[i].count);
+    if (i < n) table_add(T, rows[i].table, rows[i].k, ((u128) rows[i].word_hi << 64) | rows[i].word_lo, rows[i].count);
 }
 
 // compaction of the sparse table into rows (collect): one atomic per occupied slot
 __global__ void table_compact_kernel(DevTable T, u64 n_slots, int table, trew_hip_row *rows, u64 cap, unsigned long long *n_rows) {
     const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
+    if (i >= n_slots) {  // wide slots follow the narrow ones
+        const u64 j = i - n_slots;
+        const DevWide Wd = *T.wide;
+        if (j >= (1ull << Wd.wide_log2_slots)) return;
+        const u64 tag = Wd.wtag[j];
+        if (!(tag >> 63)) return;
+        const int t = (int) ((tag >> 59) & 7ull);
+        if (table >= 0 && t != table) return;
+        const u64 at = atomicAdd(n_rows, 1ull);
+        if (at < cap) {
+            trew_hip_row r;
+            r.k = (int32_t) ((tag >> 52) & 127ull);
+            r.table = t;
+            r.word_lo = Wd.wlo[j];
+            r.word_hi = Wd.whi[j];
+            r.count = Wd.wcount[j];
+            rows[at] = r;
+        }
+        return;
+    }
     const u64 key = T.keys[i];
     if (!key) return;
     const int t = (int) ((key >> 60) & 7ull);
@@ -1529,30 +1668,40 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
     return hipGetLastError();
 }
 
-u32 exact_lds_bytes_host(u32 cap, u32 rawwords) { return exact_lds_bytes(cap, rawwords); }
+u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_lds_bytes(cap, rawwords, wordbytes); }
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
                         const u32 *wl, u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
-    const u32 lds = exact_lds_bytes(cap, rawwords);
+    const bool wide = P.max_mer > 32;  // 128-bit words, k_mer_check_128 (kmer.cpp:100, 180)
+    const u32 lds = exact_lds_bytes(cap, rawwords, wide ? 16u : 8u);
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
     const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
     typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
-#define TREW_PICK_MODE(NWV)                                                           \
+#define TREW_PICK_MODE(NWV, WTV)                                                      \
     switch (P.mode) {                                                                 \
-    case TREW_MODE_SHORT: fn = exact_kernel<NWV, TREW_MODE_SHORT>; break;             \
-    case TREW_MODE_PAIR: fn = exact_kernel<NWV, TREW_MODE_PAIR>; break;               \
-    case TREW_MODE_LONG: fn = exact_kernel<NWV, TREW_MODE_LONG>; break;               \
-    default: fn = exact_kernel<NWV, TREW_MODE_SEGMENT>; break;                        \
+    case TREW_MODE_SHORT: fn = exact_kernel<NWV, TREW_MODE_SHORT, WTV>; break;        \
+    case TREW_MODE_PAIR: fn = exact_kernel<NWV, TREW_MODE_PAIR, WTV>; break;          \
+    case TREW_MODE_LONG: fn = exact_kernel<NWV, TREW_MODE_LONG, WTV>; break;          \
+    default: fn = exact_kernel<NWV, TREW_MODE_SEGMENT, WTV>; break;                   \
     }
-    switch (nw) {
-    case 3: TREW_PICK_MODE(3) break;
-    case 5: TREW_PICK_MODE(5) break;
-    case 10: TREW_PICK_MODE(10) break;
-    default: TREW_PICK_MODE(0) break;
+    if (!wide) {
+        switch (nw) {
+        case 3: TREW_PICK_MODE(3, u64) break;
+        case 5: TREW_PICK_MODE(5, u64) break;
+        case 10: TREW_PICK_MODE(10, u64) break;
+        default: TREW_PICK_MODE(0, u64) break;
+        }
+    } else {
+        switch (nw) {
+        case 3: TREW_PICK_MODE(3, u128) break;
+        case 5: TREW_PICK_MODE(5, u128) break;
+        case 10: TREW_PICK_MODE(10, u128) break;
+        default: TREW_PICK_MODE(0, u128) break;
+        }
     }
 #undef TREW_PICK_MODE
     // the occupancy query is not free: remember the last answer
@@ -1580,9 +1729,10 @@ hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row
     return hipGetLastError();
 }
 
-hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, int table, trew_hip_row *d_rows, u64 cap,
+hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n) {
-    hipLaunchKernelGGL(table_compact_kernel, dim3((u32) ((n_slots + 255) / 256)), dim3(256), 0, st, T, n_slots, table, d_rows, cap, d_n);
+    const u64 total = n_slots + (1ull << wide_log2_slots);
+    hipLaunchKernelGGL(table_compact_kernel, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, T, n_slots, table, d_rows, cap, d_n);
     return hipGetLastError();
 }
 
