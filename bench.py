@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="TREW_FLAG_* (debug experiments only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -51,13 +52,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % n_dev if world > 1 else 0  # one GPU per rank; wraps only in a one-GPU rehearsal
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    dev = torch.device("cuda", dev_index)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -101,11 +106,11 @@ def main():
     filt_ms.append(a)
     exact_ms.append(b)
     rows = t.collect_rows()
-    merged = allreduce_rows(rows, device=dev)
+    merged = allreduce_rows(rows, device=comm_dev)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
