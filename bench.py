@@ -127,6 +127,15 @@ def main():
         alg_bytes = n * L * 0.25 + n * 8.0
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         evals = EVALS_PER_150BP_READ * (L / 150.0) * n
+        # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
+        # (profiles/traffic.json, written by profiles/summarize.py); null when the configuration differs
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["config"] == {"reads_per_gpu": n, "read_len": L} and args.min_mer == 5 and args.max_mer == 32:
+                traffic = round(tj["kernels"][dom]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
             "value": round(value, 3),
@@ -154,7 +163,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
                 "note": "integer-issue bound, not HBM bound (SURVEY 8(d)): %.3g (window,k) evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
                         % (evals / ((f_avg + e_avg) * 1e-3), evals / ((f_avg + e_avg) * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),

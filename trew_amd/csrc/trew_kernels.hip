@@ -1040,6 +1040,11 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     // never accepted and never moves the running frequency (kmer.cpp:2225-2236).
     u64 closed_low = 0, closed_high = 0;
     u64 todo = cand & all_k_mask(kmin, kmax);
+    if (HAVE_UB) {
+        // every threshold is >= LOW_BASELINE: one ballot drops all k whose bound is already below it
+        const u64 alive = __ballot(M.ub >= P.low);  // lane l <-> k = MIN_MER + l
+        todo &= P.min_mer > 1 ? (alive << (P.min_mer - 1)) : alive;
+    }
     while (todo) {
         const int k = __ffsll((long long) todo);  // bit k-1 -> k, ascending
         todo &= todo - 1;
