@@ -466,7 +466,7 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 //   vmask [cap/64+2] u64  bit i: window i has no N
 //   emask [cap/64+2] u64  bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
 //   nmask [cap/32+2] u32  bit i = base i is not A/C/G/T or lies past the segment end
-//   raw   [2][rawwords] u32  the unit's packed triples, staged once
+//   raw   [4][rawwords] u32  packed triples of the chunk's reads (or of the two mates), staged once
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
 //   intent [32] u32  deferred histogram emissions of the pair driver
@@ -476,7 +476,7 @@ struct ExactSmem {
 };
 
 __host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
-    const u32 b = (cap / 32 + 2) * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 2 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
+    const u32 b = (cap / 32 + 2) * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 4 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
     return (b + 15u) & ~15u;
 }
 __host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords, u32 wordbytes) {
@@ -492,7 +492,7 @@ __device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_seq(sm) + (sm
 __device__ __forceinline__ u64 *sm_emask(ExactSmem sm) { return sm_vmask(sm) + (sm.cap / 64 + 2); }
 __device__ __forceinline__ u32 *sm_nmask(ExactSmem sm) { return (u32 *) (sm_emask(sm) + (sm.cap / 64 + 2)); }
 __device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm.cap / 32 + 2); }
-__device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 2 * sm.rawwords); }
+__device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 4 * sm.rawwords); }
 __device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
 __device__ __forceinline__ u32 *sm_intent(ExactSmem sm) { return (u32 *) (sm_start(sm) + sm.cap); }
 template <typename WT>
@@ -1130,10 +1130,9 @@ __device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int 
 
 // buffer_task, kmer.cpp:111-173
 template <int NW, typename WT>
-__device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
+__device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, const ReadRef &rd) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = stage_read(sm, get_read(B, unit), 0);
     const int n = (int) rd.len;
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
@@ -1207,11 +1206,10 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevBatch &B, c
 
 // TREW_MODE_SEGMENT: k_mer_check on the whole read, high -> table 0, low -> table 1
 template <int NW, typename WT>
-__device__ void run_segment(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit,
+__device__ void run_segment(ExactSmem sm, const DevParams &P, const DevTable &T, u32 unit, const ReadRef &rd,
                             const SegResults &R) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = stage_read(sm, get_read(B, unit), 0);
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
     load_segment(sm, rd, 0, s.len);
@@ -1518,32 +1516,85 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
     // dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue") -- 2 ms for 176 k reads -- so the
     // queue head is sharded 8 ways (own cache line each; chunk c of shard s = global chunk 8c+s)
     // and a wave whose shard runs dry steals from the next one.
-    constexpr u32 kChunk = 1, kShards = 8, kHeadStride = 32;
+    // A chunk is kChunk consecutive worklist items: their reads are fetched together so that the
+    // dependent global round trips (queue head -> worklist entry -> read words) are paid once
+    // per chunk, not once per read (measured: 0.40 ms of a 1.3 ms launch was this latency chain).
+    constexpr u32 kChunk = 4, kShards = 8, kHeadStride = 32;
     u32 *heads = wl_count + kHeadStride;
     const u32 my = blockIdx.x & (kShards - 1);
+    const u32 lane = lane_id();
     for (u32 attempt = 0; attempt < kShards; attempt++) {
         const u32 sh = (my + attempt) & (kShards - 1);
         for (;;) {
-        u32 c = 0;
-        if (lane_id() == 0) c = atomicAdd(&heads[sh * kHeadStride], 1u);
-        c = rfl(c);
-        const u64 w0l = ((u64) c * kShards + sh) * kChunk;
-        if (w0l >= n) break;
-        const u32 w0 = (u32) w0l;
-        const u32 w1 = w0 + kChunk < n ? w0 + kChunk : n;
-        for (u32 w = w0; w < w1; w++) {
-        const u32 it = wl[w];
-        // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
-        if (MODE == TREW_MODE_SHORT)
-            run_short<NW, WT>(sm, P, B, T, it);
-        else if (MODE == TREW_MODE_SEGMENT)
-            run_segment<NW, WT>(sm, P, B, T, it, R);
-        else if (MODE == TREW_MODE_LONG)
-            run_long<NW, WT>(sm, P, B, T, it);
-        else
-            run_pair<NW, WT>(sm, P, B, T, it);
-        __syncthreads();
-        }
+            u32 c = 0;
+            if (lane == 0) c = atomicAdd(&heads[sh * kHeadStride], 1u);
+            c = rfl(c);
+            const u64 w0l = ((u64) c * kShards + sh) * kChunk;
+            if (w0l >= n) break;
+            const u32 w0 = (u32) w0l;
+            const u32 nit = (w0 + kChunk < n ? w0 + kChunk : n) - w0;
+            u32 units[kChunk];
+#pragma unroll
+            for (u32 t = 0; t < kChunk; t++) units[t] = t < nit ? wl[w0 + t] : 0u;
+            // one instantiation per mode: the short-read kernel does not carry the pair driver's registers
+            if (MODE == TREW_MODE_SHORT || MODE == TREW_MODE_SEGMENT) {
+                ReadRef rds[kChunk];
+                u32 head[kChunk];  // word `lane` of each read
+#pragma unroll
+                for (u32 t = 0; t < kChunk; t++) {
+                    rds[t].w = B.words;
+                    rds[t].len = 0;
+                    rds[t].nw = 0;
+                    if (t < nit) rds[t] = get_read(B, units[t]);
+                }
+#pragma unroll
+                for (u32 t = 0; t < kChunk; t++) head[t] = lane < 3u * rds[t].nw ? rds[t].w[lane] : 0u;
+                __syncthreads();  // the previous chunk no longer reads raw[]
+                u32 *meta = sm_intent(sm);  // per item: length, unit, word offset of the read (lo, hi), staged flag
+#pragma unroll
+                for (u32 t = 0; t < kChunk; t++) {
+                    const u32 nwords = 3u * rds[t].nw;
+                    const bool fits = nwords <= sm.rawwords;
+                    if (fits) {
+                        u32 *dst = sm_raw(sm) + t * sm.rawwords;
+                        if (lane < nwords) dst[lane] = head[t];
+                        for (u32 j = lane + 64u; j < nwords; j += 64u) dst[j] = rds[t].w[j];
+                    }
+                    if (lane == 0) {
+                        const u64 off = (u64) (rds[t].w - B.words);
+                        meta[5 * t + 0] = rds[t].len;
+                        meta[5 * t + 1] = units[t];
+                        meta[5 * t + 2] = (u32) off;
+                        meta[5 * t + 3] = (u32) (off >> 32);
+                        meta[5 * t + 4] = fits ? 1u : 0u;
+                    }
+                }
+                __syncthreads();
+                for (u32 t = 0; t < nit; t++) {  // not unrolled: one copy of the driver
+                    ReadRef rd;
+                    rd.len = rfl(meta[5 * t + 0]);
+                    rd.nw = (rd.len + 31u) >> 5;
+                    const u32 unit = rfl(meta[5 * t + 1]);
+                    const u64 off = ((u64) rfl(meta[5 * t + 3]) << 32) | rfl(meta[5 * t + 2]);
+                    rd.w = rfl(meta[5 * t + 4]) ? (const u32 *) (sm_raw(sm) + t * sm.rawwords) : B.words + off;
+                    if (MODE == TREW_MODE_SHORT)
+                        run_short<NW, WT>(sm, P, T, rd);
+                    else
+                        run_segment<NW, WT>(sm, P, T, unit, rd, R);
+                    __syncthreads();
+                }
+            } else {
+#pragma unroll
+                for (u32 t = 0; t < kChunk; t++) {
+                    if (t < nit) {
+                        if (MODE == TREW_MODE_LONG)
+                            run_long<NW, WT>(sm, P, B, T, units[t]);
+                        else
+                            run_pair<NW, WT>(sm, P, B, T, units[t]);
+                        __syncthreads();
+                    }
+                }
+            }
         }
     }
 }
