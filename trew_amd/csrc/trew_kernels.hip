@@ -470,14 +470,19 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
 //   intent [32] u32  deferred histogram emissions of the pair driver
+//   ckey/cpart/ccnt [kCacheSlots]  the wave's private count cache (see cached_add)
 //   canon [cap]  WT   per run (fast path) or per window (fallback); WT = u64 (k <= 32) or u128
 struct ExactSmem {
     u32 cap, rawwords;
 };
 
-__host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
+constexpr u32 kCacheSlots = 128;
+__host__ __device__ inline u32 exact_lds_precache(u32 cap, u32 rawwords) {  // everything before the count cache, 16-byte aligned
     const u32 b = (cap / 32 + 2) * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 4 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
     return (b + 15u) & ~15u;
+}
+__host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
+    return exact_lds_precache(cap, rawwords) + kCacheSlots * 16u;
 }
 __host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords, u32 wordbytes) {
     return exact_lds_fixed(cap, rawwords) + cap * wordbytes + 16;
@@ -495,6 +500,9 @@ __device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm
 __device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 4 * sm.rawwords); }
 __device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
 __device__ __forceinline__ u32 *sm_intent(ExactSmem sm) { return (u32 *) (sm_start(sm) + sm.cap); }
+__device__ __forceinline__ u64 *sm_ckey(ExactSmem sm) { return (u64 *) (lds0() + exact_lds_precache(sm.cap, sm.rawwords)); }
+__device__ __forceinline__ u32 *sm_cpart(ExactSmem sm) { return (u32 *) (sm_ckey(sm) + kCacheSlots); }
+__device__ __forceinline__ u32 *sm_ccnt(ExactSmem sm) { return sm_cpart(sm) + kCacheSlots; }
 template <typename WT>
 __device__ __forceinline__ WT *sm_canon(ExactSmem sm) { return (WT *) (lds0() + exact_lds_fixed(sm.cap, sm.rawwords)); }
 
@@ -865,6 +873,59 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
     __syncthreads();
 }
 
+// Wave-private count cache in LDS.  A few keys (the dominant motif's classes) receive an add from
+// almost every surviving read; as device atomics on one address they serialise chip-wide
+// (0.4 ms of a 1.3 ms launch, measured with TREW_FLAG_DEBUG_NO_EMIT).  Each wave keeps the first
+// kCacheSlots distinct keys it meets in LDS (insert-only, no eviction: the hot keys show up in the
+// first reads), adds to them with LDS atomics and flushes once when it runs out of work.
+// Entry = the 64-bit table key of table_add + the 9 partition bits of the word.
+__device__ __forceinline__ void cached_add(ExactSmem sm, DevTable T, int table, int k, u64 word, u32 cnt) {
+    if (T.log2_part_slots == 0xffffffffu) return;  // TREW_FLAG_DEBUG_NO_EMIT
+    const u32 part = (u32) (word & ((1u << kTablePartBits) - 1u));
+    const u64 gkey = (1ull << 63) | ((u64) table << 60) | ((u64) (k - 1) << 55) | (word >> kTablePartBits);
+    const u32 slot = (u32) (hash64(gkey ^ ((u64) part << 40)) >> 20) & (kCacheSlots - 1u);
+    u64 *ckey = sm_ckey(sm);
+    u32 *cpart = sm_cpart(sm), *ccnt = sm_ccnt(sm);
+    u64 ek = ckey[slot];
+    if (ek == 0) {
+        const u64 prev = atomicCAS((unsigned long long *) &ckey[slot], 0ull, gkey);
+        if (prev == 0) {
+            cpart[slot] = part;  // LDS operations of one wave execute in order: visible to the read below
+            ek = gkey;
+        } else {
+            ek = prev;
+        }
+    }
+    if (ek == gkey && cpart[slot] == part)
+        atomicAdd(&ccnt[slot], cnt);
+    else
+        table_add(T, table, k, word, (u64) cnt);
+}
+__device__ __forceinline__ void cached_add(ExactSmem sm, DevTable T, int table, int k, u128 word, u32 cnt) {
+    if (k <= 32)
+        cached_add(sm, T, table, k, (u64) word, cnt);
+    else
+        table_add(T, table, k, word, (u64) cnt);
+}
+__device__ void cache_clear(ExactSmem sm) {
+    for (u32 i = lane_id(); i < kCacheSlots; i += 64) {
+        sm_ckey(sm)[i] = 0;
+        sm_cpart(sm)[i] = 0;
+        sm_ccnt(sm)[i] = 0;
+    }
+    __syncthreads();
+}
+__device__ void cache_flush(ExactSmem sm, DevTable T) {
+    __syncthreads();
+    for (u32 i = lane_id(); i < kCacheSlots; i += 64) {
+        const u64 gkey = sm_ckey(sm)[i];
+        if (gkey) {
+            const u64 word = ((gkey & ((1ull << 55) - 1ull)) << kTablePartBits) | sm_cpart(sm)[i];
+            table_add(T, (int) ((gkey >> 60) & 7ull), (int) ((gkey >> 55) & 31ull) + 1, word, (u64) sm_ccnt(sm)[i]);
+        }
+    }
+}
+
 // add every class of the k just evaluated to the tables in table_mask (bit t).
 // strand_canon: key = MIN(w, rot(rc(w))) (k_mer_target, kmer.cpp:1979-1988) else the
 // rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
@@ -879,7 +940,7 @@ __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n
                 const WT rc = min_rotation<WT>(revcomp(w, k), k);
                 w = rc < w ? rc : w;
             }
-            for (u32 tm = table_mask; tm; tm &= tm - 1) table_add(T, __ffs((int) tm) - 1, k, w, c);
+            for (u32 tm = table_mask; tm; tm &= tm - 1) cached_add(sm, T, __ffs((int) tm) - 1, k, w, c);
         }
     }
 }
@@ -1511,6 +1572,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
     sm.rawwords = rawwords;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
+    cache_clear(sm);
     // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from device counters
     // instead of a static stride.  One returning atomic on a single word saturates at ~88
     // dequeues/us on MI355X (MI355X_MICROARCH.md, row "dequeue") -- 2 ms for 176 k reads -- so the
@@ -1597,6 +1659,7 @@ __global__ __launch_bounds__(64) void exact_kernel(DevParams P, DevBatch B, DevT
             }
         }
     }
+    cache_flush(sm, T);
 }
 
 // ------------------------------------------------------------------ table maintenance
