@@ -373,3 +373,88 @@ def test_long_fixture_is_empty():
         got = t.collect()
     assert all(len(v) == 0 for v in got.values())
     assert got == O.run_long(O.OracleParams(), reads)
+
+
+# ---------------------------------------------------------------- randomized cross-checks, every mode
+def _fuzz_reads(rnd, count, maxlen):
+    from helpers import mutate, periodic
+
+    out = []
+    for _ in range(count):
+        n = rnd.choice([rnd.randint(1, 60), rnd.randint(60, 260), rnd.randint(1, maxlen)])
+        kind = rnd.random()
+        if kind < 0.2:
+            s = "".join(rnd.choice("ACGT") for _ in range(n))
+        elif kind < 0.3:
+            s = "".join(rnd.choice("AT") for _ in range(n))  # low complexity: many runs, many classes
+        else:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 70)))
+            s = periodic(unit, n, rnd.randint(0, 11))
+            s = mutate(s, rnd, p_sub=rnd.choice([0, 0.01, 0.05, 0.2]), p_n=rnd.choice([0, 0, 0.01, 0.1]))
+            if rnd.random() < 0.3:  # junction with a second repeat or random tail
+                cut = rnd.randint(0, n)
+                u2 = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(2, 40)))
+                s = s[:cut] + periodic(u2, n - cut)
+        if rnd.random() < 0.05:
+            s = s.lower()
+        out.append(s[:n].encode())
+    return out
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_FUZZ_SEEDS", "40"))))
+def test_fuzz_all_modes(seed):
+    import random
+
+    rnd = random.Random(1000 + seed)
+    mn = rnd.choice([3, 4, 5, 6, 9, 17])
+    mx = rnd.choice([mn, mn + 1, 12, 20, 31, 32, 33, 48, 63, 64])
+    mx = max(mn, mx)
+    low = rnd.choice([0.5, 0.3, 0.51, 2 / 3, 0.75, 1.0])
+    high = max(low, rnd.choice([0.8, 0.6, 0.9, 1.0]))
+    kw = dict(min_mer=mn, max_mer=mx, low=low, high=high)
+    p = O.OracleParams(**kw)
+    # short
+    reads = _fuzz_reads(rnd, 250, 1000)
+    want = O.run_short(p, reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, **kw) as t:
+        t.submit_reads(reads)
+        t.wait()
+        assert t.collect() == want, ("short", kw)
+    # pair
+    r1 = _fuzz_reads(rnd, 150, 400)
+    r2 = [_revcomp(r) if rnd.random() < 0.6 else x for r, x in zip(r1, _fuzz_reads(rnd, 150, 400))]
+    want = O.run_pair(p, r1, r2)
+    both = [x for pr in zip(r1, r2) for x in pr]
+    with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=len(both) + 8, max_batch_words=1 << 22, **kw) as t:
+        t.submit_reads(both)
+        t.wait()
+        assert t.collect() == want, ("pair", kw)
+    # long
+    sl = rnd.choice([2 * mx, 150, 200, 2 * mx + 7])
+    sl = max(sl, 2 * mx)
+    pl = O.OracleParams(slice_len=sl, **kw)
+    lr = [r for r in _fuzz_reads(rnd, 120, 4000) if len(r) >= sl]
+    want = O.run_long(pl, lr)
+    with T.TrewHip(mode=T.MODE_LONG, slice_length=sl, max_batch_reads=len(lr) + 8, max_batch_words=1 << 22, **kw) as t:
+        t.submit_reads(lr)
+        t.wait()
+        assert t.collect() == want, ("long", kw, sl)
+
+
+def test_regressions_found_by_fuzzing():
+    # (1) LDS mask words: a 176-base segment uses the NW=10 kernels but only 3 mask words; the run-based
+    #     path once wrote past them and cleared the N mask of the first bases (leading N became valid)
+    seg = b"NCGTACCGACT" + b"AGGG" * 41 + b"A"
+    for mn, mx in ((17, 48), (5, 32)):
+        assert T.k_mer_check(seg, mn, mx, 0.3, 0.9) == O.segment_check(O.OracleParams(min_mer=mn, max_mer=mx, low=0.3, high=0.9), seg)
+    # (2) long mode: the middle slice (SLICE_LENGTH + remainder) is longer than the first/last slices
+    #     the prefilter looks at; the kernels must be sized for it
+    unit = "TTCCAAGTATCCTGTTATCGAGTGAA"
+    read = ("ACGT" * 50 + (unit * 30)[:576]).encode()
+    p = O.OracleParams(min_mer=9, max_mer=31, low=1.0, high=1.0, slice_len=200)
+    with T.TrewHip(mode=T.MODE_LONG, slice_length=200, min_mer=9, max_mer=31, low=1.0, high=1.0, max_batch_reads=8, max_batch_words=1 << 16) as t:
+        t.submit_reads([read])
+        t.wait()
+        got = t.collect()
+    want = O.run_long(p, [read])
+    assert got == want and sum(len(v) for v in want.values()) > 0

@@ -256,6 +256,8 @@ static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_s
     // longest segment of one unit, from the same geometry function the kernels use
     auto unit_seg = [&](u32 n1, u32 n2) {
         u32 m = 0;
+        // long mode also walks the interior slices: the middle one carries the remainder (kmer.cpp:790-798)
+        if (mode == TREW_MODE_LONG && (int) n1 >= SL) m = (u32) SL + n1 % (u32) SL;
         for (int slot = 0; slot < mode_slots(mode); slot++) {
             const Segment sg = get_segment(mode, slot, n1, n2, MINM, MAXM, SL);
             if (sg.valid) m = std::max(m, sg.len);

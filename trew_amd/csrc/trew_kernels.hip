@@ -1128,9 +1128,13 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
             if (W > 0) {
                 __syncthreads();
                 u64 *vm = sm_vmask(sm), *em = sm_emask(sm);
-                const int nq = (NWB + 1) / 2;
+                // the LDS mask arrays hold cap/64 + 2 words: never write past them when the
+                // instantiation's NW covers more bits than this batch's segments need
+                const int nq_all = (NWB + 1) / 2, nq_fit = (int) (sm.cap / 64u) + 1;
+                const int nq = nq_all < nq_fit ? nq_all : nq_fit;
 #pragma unroll
-                for (int q = 0; q < nq; q++) {
+                for (int q = 0; q < nq_all; q++) {
+                    if (q >= nq) break;
                     const u32 v0 = (u32) __builtin_amdgcn_readlane((int) M.V[2 * q], src);
                     const u32 e0 = (u32) __builtin_amdgcn_readlane((int) M.E[2 * q], src);
                     const u32 v1 = 2 * q + 1 < NWB ? (u32) __builtin_amdgcn_readlane((int) M.V[2 * q + 1 < NWB ? 2 * q + 1 : 0], src) : 0u;
