@@ -458,3 +458,28 @@ def test_regressions_found_by_fuzzing():
         got = t.collect()
     want = O.run_long(p, [read])
     assert got == want and sum(len(v) for v in want.values()) > 0
+
+
+@pytest.mark.parametrize("read_len,mn,mx", [(150, 5, 32), (151, 5, 32), (100, 5, 32), (127, 5, 32), (128, 5, 32), (60, 3, 20),
+                                             (250, 5, 32), (300, 4, 64), (75, 5, 32), (36, 5, 12), (1000, 5, 32), (97, 6, 40)])
+def test_device_resident_uniform_batches(read_len, mn, mx):
+    """Device-generated, device-resident uniform batches (the bench layout) at odd geometries:
+    whole-read segment present/absent, halves of 18..500 bases, narrow and wide words."""
+    n = 3000 if read_len <= 300 else 600
+    buf, st, nd = capi.synth_short_ascii(77 + read_len, 5, n, read_len)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(min_mer=mn, max_mer=mx), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, min_mer=mn, max_mer=mx, max_batch_reads=n, max_batch_words=16, n_slots=2) as t:
+        stride = 3 * ((read_len + 31) // 32)
+        d = t.malloc(n * stride * 4 + 64)
+        t.synth_short_device(77 + read_len, 5, n, read_len, d)
+        half = n // 2
+        # two sub-batches on two slots/streams, second one offset into the buffer
+        t.submit(t.device_uniform_batch(d, half, read_len), 0)
+        t.submit(t.device_uniform_batch(d + half * stride * 4, n - half, read_len), 1)
+        t.wait(0)
+        t.wait(1)
+        got = t.collect()
+        t.free(d)
+    assert got == want
+    assert sum(len(v) for v in want.values()) > 0
