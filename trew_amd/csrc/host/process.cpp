@@ -240,24 +240,23 @@ static void read_fastq_thread(FileReader &fr, ChunkQueue *q, bool long_mode, int
         const int bytes_read = fr.read(buffer + shift, LENGTH - 1 - shift);
         const int total = (bytes_read > 0 ? bytes_read : 0) + shift;
         buffer[total] = '\0';
-        for (int i = 0; i < total; i++) {
-            if (buffer[i] == '\n') {
-                num += 1;
-                if ((num & 3) == 2) {
-                    const int len = (i - 1) - (idx + 1) + 1;
-                    if (long_mode) {
-                        if (len >= slice_length) {  // kmer.cpp:1184
-                            ch->st1.push_back(idx + 1);
-                            ch->nd1.push_back(i - 1);
-                        }
-                    } else {
-                        if (len > MAX_SEQ) die("This mode is designed for short-read sequencing. Please use 'trew long'.");  // kmer.cpp:1006-1009
+        for (const char *nl = (const char *) memchr(buffer, '\n', (size_t) total); nl; nl = (const char *) memchr(nl + 1, '\n', (size_t) (buffer + total - nl - 1))) {
+            const int i = (int) (nl - buffer);
+            num += 1;
+            if ((num & 3) == 2) {
+                const int len = (i - 1) - (idx + 1) + 1;
+                if (long_mode) {
+                    if (len >= slice_length) {  // kmer.cpp:1184
                         ch->st1.push_back(idx + 1);
                         ch->nd1.push_back(i - 1);
                     }
+                } else {
+                    if (len > MAX_SEQ) die("This mode is designed for short-read sequencing. Please use 'trew long'.");  // kmer.cpp:1006-1009
+                    ch->st1.push_back(idx + 1);
+                    ch->nd1.push_back(i - 1);
                 }
-                idx = i;
             }
+            idx = i;
         }
         ch->buffer1 = buffer;
         if (bytes_read <= 0) {
@@ -317,17 +316,17 @@ static void read_pair_fastq_thread(FileReader &f1, FileReader &f2, ChunkQueue *q
             }
             const int total = x.bytes_read + x.shift;
             x.buffer[total] = '\0';
-            for (int i = 0; i < total; i++) {
-                if (x.buffer[i] == '\n') {
-                    x.num += 1;
-                    if ((x.num & 3) == 2) {
-                        if ((i - 1) - (x.idx + 1) + 1 > MAX_SEQ)  // the reference leaves pair mode unchecked
-                            die("This mode is designed for short-read sequencing. Please use 'trew long'.");
-                        x.st.push_back(x.idx + 1);
-                        x.nd.push_back(i - 1);
-                    }
-                    x.idx = i;
+            for (const char *nl = (const char *) memchr(x.buffer, '\n', (size_t) total); nl;
+                 nl = (const char *) memchr(nl + 1, '\n', (size_t) (x.buffer + total - nl - 1))) {
+                const int i = (int) (nl - x.buffer);
+                x.num += 1;
+                if ((x.num & 3) == 2) {
+                    if ((i - 1) - (x.idx + 1) + 1 > MAX_SEQ)  // the reference leaves pair mode unchecked
+                        die("This mode is designed for short-read sequencing. Please use 'trew long'.");
+                    x.st.push_back(x.idx + 1);
+                    x.nd.push_back(i - 1);
                 }
+                x.idx = i;
             }
         }
         Chunk *ch = new Chunk();

@@ -553,10 +553,32 @@ struct PackLut {
 };
 const PackLut g_lut;
 
+// 32 bases -> {lo, hi, nmask} with AVX2 compares + movemask (about 10x the table loop)
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) inline void pack32_avx2(const unsigned char *q, uint32_t *out) {
+    const __m256i c = _mm256_and_si256(_mm256_loadu_si256((const __m256i *) q), _mm256_set1_epi8((char) 0xDF));  // upper-case
+    const __m256i a = _mm256_cmpeq_epi8(c, _mm256_set1_epi8('A')), cc = _mm256_cmpeq_epi8(c, _mm256_set1_epi8('C'));
+    const __m256i g = _mm256_cmpeq_epi8(c, _mm256_set1_epi8('G')), t = _mm256_cmpeq_epi8(c, _mm256_set1_epi8('T'));
+    // letters only: 0xDF folding must not turn e.g. 'a'-0x20 twins of non-letters into hits: A/C/G/T & a/c/g/t are the only preimages
+    const uint32_t ma = (uint32_t) _mm256_movemask_epi8(a), mc = (uint32_t) _mm256_movemask_epi8(cc);
+    const uint32_t mg = (uint32_t) _mm256_movemask_epi8(g), mt = (uint32_t) _mm256_movemask_epi8(t);
+    out[0] = mg | ma;             // lo bit: G=1, A=3
+    out[1] = mc | ma;             // hi bit: C=2, A=3
+    out[2] = ~(ma | mc | mg | mt);  // everything else is "N"
+}
+#endif
+
 // one read -> triples; returns words written
 inline uint64_t pack_one(const unsigned char *p, uint64_t len, uint32_t *out) {
     const uint64_t nw = (len + 31) / 32;
-    for (uint64_t j = 0; j < nw; j++) {
+    uint64_t j = 0;
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2)
+        for (; 32 * (j + 1) <= len; j++) pack32_avx2(p + 32 * j, out + 3 * j);
+#endif
+    for (; j < nw; j++) {
         uint32_t lo = 0, hi = 0, nm = 0;
         const uint64_t m = std::min<uint64_t>(32, len - 32 * j);
         const unsigned char *q = p + 32 * j;
