@@ -177,6 +177,4 @@ TREW_HD inline int mode_slots(int mode) {
     return mode == TREW_MODE_SHORT ? 3 : mode == TREW_MODE_PAIR ? 6 : mode == TREW_MODE_LONG ? 2 : 1;
 }
 
-// launchers implemented in trew_kernels.hip
-struct LaunchTiming;
 }  // namespace trew

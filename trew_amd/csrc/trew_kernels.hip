@@ -2,7 +2,7 @@
 //
 // Two kernels per batch, both pure integer (no MFMA -- this is bit/byte work):
 //
-//  1. filter_kernel<NW>  one LANE per read.  Bit-parallel, branch-free upper
+//  1. filter_kernel<NW>  one LANE per read (persistent blocks).  Bit-parallel upper
 //     bound on max-class/COUNT for every k in [MIN_MER, MAX_MER] of every
 //     segment of the read.  Windows in one rotation class (get_rot_seq,
 //     kmer.cpp:1815-1823) have the same base composition, hence the same three
@@ -16,11 +16,12 @@
 //
 //  2. exact_kernel       one WAVEFRONT (64 lanes) per surviving read.  Restates
 //     k_mer_check / k_mer_target / buffer_task* exactly, but only for candidate
-//     k: lanes own windows, canonical rotations go to LDS, class sizes come
-//     from an all-pairs LDS-broadcast compare, MAX_SEQ's "first class to reach
-//     the maximum" tie-break (strict '<' at kmer.cpp:2202) is the class whose
-//     last window comes first.  Histograms are added to a device-resident
-//     open-addressing table with 64-bit CAS keys.
+//     k: the same bucket bound for all k at once (lane = k) prunes against the running
+//     thresholds; survivors are split into runs of adjacent same-class windows (Lemma A),
+//     one canonical rotation per run, runs merged by readlane broadcasts; MAX_SEQ's
+//     "first class to reach the maximum" tie-break (strict '<' at kmer.cpp:2202) is the
+//     class whose last window comes first.  Histograms go through a wave-private LDS count
+//     cache into a device-resident open-addressing table with 64-bit CAS keys.
 //
 // No CUDA shims, no dual paths: HIP for gfx950 only.
 #include <hip/hip_runtime.h>
@@ -91,12 +92,6 @@ __device__ __forceinline__ void load_planes(const ReadRef &rd, u32 s, u32 (&lo)[
 }
 
 // ------------------------------------------------------------------ prefilter
-template <int NW>
-__device__ __forceinline__ void shr1(u32 (&x)[NW]) {
-#pragma unroll
-    for (int j = 0; j < NW - 1; j++) x[j] = alignbit(x[j + 1], x[j], 1);
-    x[NW - 1] >>= 1;
-}
 
 // exclusive prefix parity of f over bits 0..32*NW-1: P[i] = XOR_{t<i} f[t]
 template <int NW>
@@ -1075,15 +1070,6 @@ __device__ __forceinline__ u64 multiples_mask(int k) {
     u64 m = 0;
     for (int j = k; j <= 64; j += k) m |= 1ull << (j - 1);
     return m;
-}
-
-__device__ __forceinline__ bool divides_any(int k, u64 accepted) {
-    while (accepted) {
-        const int tk = __ffsll((long long) accepted);  // bit tk-1 -> k value tk
-        accepted &= accepted - 1;
-        if (k % tk == 0) return true;
-    }
-    return false;
 }
 
 // selection loops of k_mer_check, kmer.cpp:2221-2258, run online over ascending
