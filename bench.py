@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="TREW_FLAG_* (debug experiments only)")
+    ap.add_argument("--mode", default="short", choices=["short", "pair", "long"],
+                    help="short = the BASELINE metric (config 2); pair / long = configs 3 / 4, reported for information")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -69,12 +71,25 @@ def main():
 
     n, L = args.reads, args.read_len
     stride = 3 * ((L + 31) // 32)
-    t = T.TrewHip(mode=T.MODE_SHORT, min_mer=args.min_mer, max_mer=args.max_mer, device=dev.index, n_slots=1,
-                  max_batch_words=16, max_batch_reads=n, table_log2_slots=20, flags=args.flags)
-    d_words = t.malloc(n * stride * 4 + 64)
     first_read = rank * n  # contiguous read-index ranges per rank
-    t.synth_short_device(SEED, first_read, n, L, d_words)
-    batch = t.device_uniform_batch(d_words, n, L)
+    dev_mode = {"short": T.MODE_SHORT, "pair": T.MODE_PAIR, "long": T.MODE_LONG}[args.mode]
+    n_reads_dev = 2 * n if args.mode == "pair" else n  # --reads counts pairs in pair mode
+    t = T.TrewHip(mode=dev_mode, min_mer=args.min_mer, max_mer=args.max_mer, device=dev.index, n_slots=1,
+                  max_batch_words=16, max_batch_reads=n_reads_dev, table_log2_slots=20, flags=args.flags)
+    to_free = []
+    if args.mode == "short":
+        d_words = t.malloc(n * stride * 4 + 64)
+        t.synth_short_device(SEED, first_read, n, L, d_words)
+        batch = t.device_uniform_batch(d_words, n, L)
+        bases_per_step = n * L
+    elif args.mode == "pair":
+        d_words = t.malloc(2 * n * stride * 4 + 64)
+        t.synth_pair_device(SEED, first_read, n, L, d_words)
+        batch = t.device_uniform_batch(d_words, 2 * n, L)
+        bases_per_step = 2 * n * L
+    else:
+        batch, to_free, bases_per_step = t.synth_long_device(SEED, first_read, n)
+        d_words = to_free[0]
 
     def barrier():
         if world > 1:
@@ -114,7 +129,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    bases = float(world) * n * L * args.steps
+    bases = float(world) * bases_per_step * args.steps
     value = bases / dt / 1e9
     ms_per_step = dt / args.steps * 1e3
 
@@ -123,21 +138,24 @@ def main():
         f_avg = sum(filt_ms) / len(filt_ms)
         e_avg = sum(exact_ms) / len(exact_ms)
         dom, dom_ms = ("filter_kernel", f_avg) if f_avg >= e_avg else ("exact_kernel", e_avg)
-        # algorithmic bytes per launch: 0.25 B per base (2-bit input) + 8 B per read (offset/length), SURVEY 8(d)
-        alg_bytes = n * L * 0.25 + n * 8.0
+        # algorithmic bytes per launch: 0.25 B per base (2-bit input) + 8 B per read (offset/length), SURVEY 8(d).
+        # Long mode counts every base of a read although only the outer slices are touched.
+        alg_bytes = bases_per_step * 0.25 + n_reads_dev * 8.0
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        evals = EVALS_PER_150BP_READ * (L / 150.0) * n
+        evals = EVALS_PER_150BP_READ * (L / 150.0) * n if args.mode != "long" else 7420.0 * n
         # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
         # (profiles/traffic.json, written by profiles/summarize.py); null when the configuration differs
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj["config"] == {"reads_per_gpu": n, "read_len": L} and args.min_mer == 5 and args.max_mer == 32:
+            if args.mode == "short" and tj["config"] == {"reads_per_gpu": n, "read_len": L} and args.min_mer == 5 and args.max_mer == 32:
                 traffic = round(tj["kernels"][dom]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             traffic = None
         out = {
-            "metric": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
+            "metric": {"short": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
+                       "pair": "Gbases/s scanned (short %d %d --paired_end, 2x%d bp)" % (args.min_mer, args.max_mer, L),
+                       "long": "Gbases/s scanned (long %d %d, ONT-like reads, every base counted)" % (args.min_mer, args.max_mer)}[args.mode],
             "value": round(value, 3),
             "unit": "Gbases/s",
             "n_gpus": world,
@@ -150,8 +168,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "short %d %d, %d synthetic %d bp reads per GPU (TTAGGG-seeded, seed %d)" % (
-                    args.min_mer, args.max_mer, n, L, SEED),
+                "workload": {"short": "short %d %d, %d synthetic %d bp reads per GPU (TTAGGG-seeded, seed %d)" % (args.min_mer, args.max_mer, n, L, SEED),
+                             "pair": "short %d %d --paired_end, %d synthetic 2x%d bp pairs per GPU (seed %d)" % (args.min_mer, args.max_mer, n, L, SEED),
+                             "long": "long %d %d, %d synthetic ONT-like reads per GPU (N50 ~20 kb, %.2f Gbases, seed %d)" % (args.min_mer, args.max_mer, n, bases_per_step / 1e9, SEED)}[args.mode],
                 "reads_per_gpu": n,
                 "read_len": L,
                 "parallelism": "dp%d read-sharded, one table all-reduce" % world,
@@ -177,29 +196,53 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle as O
 
-        m = min(args.cpu_reads, n)
-        buf, st, nd = capi.synth_short_ascii(SEED, 0, m, L)
         cores = os.cpu_count() or 1
-        want, cpu_dt = O.run_short_mt_timed(O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer), buf, st, nd, cores)
+        op = O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer)
         t.reset_tables()
-        t.submit(t.device_uniform_batch(d_words, m, L), 0)
+        if args.mode == "short":
+            m = min(args.cpu_reads, n)
+            buf, st, nd = capi.synth_short_ascii(SEED, 0, m, L)
+            want, cpu_dt = O.run_short_mt_timed(op, buf, st, nd, cores)
+            t.submit(t.device_uniform_batch(d_words, m, L), 0)
+            sample_bases, used = m * L, cores
+            what = "first %d reads" % m
+        elif args.mode == "pair":
+            m = min(args.cpu_reads // 10, n)
+            b1, b2, st, nd = capi.synth_pair_ascii(SEED, 0, m, L)
+            c0 = time.perf_counter()
+            want = O.run_pair(op, [b1[s:e + 1] for s, e in zip(st, nd)], [b2[s:e + 1] for s, e in zip(st, nd)])
+            cpu_dt = time.perf_counter() - c0
+            t.submit(t.device_uniform_batch(d_words, 2 * m, L), 0)
+            sample_bases, used = 2 * m * L, 1
+            what = "first %d pairs" % m
+        else:
+            m = min(args.cpu_reads // 100, n)
+            buf, st, nd = capi.synth_long_ascii(SEED, 0, m)
+            c0 = time.perf_counter()
+            want = O.run_long(op, [buf[s:e + 1] for s, e in zip(st, nd)])
+            cpu_dt = time.perf_counter() - c0
+            sub = capi.Batch(batch.words, batch.n_words, batch.offsets, batch.lengths, 0, 0, m, 1, batch.max_length)
+            t.submit(sub, 0)
+            sample_bases, used = int((nd - st + 1).sum()), 1
+            what = "first %d reads" % m
         t.wait(0)
         got = t.collect()
         out["cpu_baseline"] = {
-            "value": round(m * L / cpu_dt / 1e9, 6),
+            "value": round(sample_bases / cpu_dt / 1e9, 6),
             "unit": "Gbases/s",
-            "cores": cores,
+            "cores": used,
             "kind": "port",
-            "sample": "first %d reads of the same synthetic workload (%.1f Mbases), oracle/trew_oracle.c with %d threads, %.1f s" % (
-                m, m * L / 1e6, cores, cpu_dt),
+            "sample": "%s of the same synthetic workload (%.1f Mbases), oracle/trew_oracle.c with %d thread(s), %.1f s" % (
+                what, sample_bases / 1e6, used, cpu_dt),
         }
         out["parity"] = bool(got == want)
-        out["parity_note"] = "GPU tables vs CPU oracle on the %d-read sample: %s" % (m, "bit-exact" if got == want else "MISMATCH")
+        out["parity_note"] = "GPU tables vs CPU oracle on the sample: %s" % ("bit-exact" if got == want else "MISMATCH")
 
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    t.free(d_words)
+    for ptr in (to_free or [d_words]):
+        t.free(ptr)
     t.close()
     if world > 1:
         dist.destroy_process_group()

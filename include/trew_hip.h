@@ -169,6 +169,14 @@ int trew_synth_pair_ascii(uint64_t seed, uint64_t first_pair, uint64_t n_pairs, 
 int trew_synth_pair_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
                            uint32_t read_len, uint32_t *d_words);
 
+/* long reads (config 4): lengths from clip(lognormal(9.413, 0.7), 1000, 200000), 5 % with a 2-6 kb
+ * (TTAGGG)n 3' tail (5 % substitutions), half reverse-complemented.  lengths first, then the caller
+ * lays the reads out (byte offsets of the ASCII rows / u32 word offsets of the packed triples). */
+int trew_synth_long_lengths(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t *lengths);
+int trew_synth_long_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, const uint64_t *byte_offsets, char *out);
+int trew_synth_long_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                           const uint32_t *d_offsets, uint32_t *d_words);
+
 /* device memory helpers so that a non-C++ host can keep batches resident */
 int trew_hip_malloc(trew_hip_ctx *ctx, uint64_t bytes, void **d_ptr);
 int trew_hip_free(trew_hip_ctx *ctx, void *d_ptr);

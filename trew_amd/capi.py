@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "trew_synth_short_ascii", "trew_synth_short_device", "trew_synth_pair_ascii", "trew_synth_pair_device",
     "trew_hip_malloc", "trew_hip_free", "trew_hip_memcpy_h2d", "trew_hip_memcpy_d2h", "trew_hip_abi_version",
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
+    "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
 )
 
 
@@ -107,6 +108,9 @@ def load():
     lib.trew_synth_short_device.argtypes = [vp, u64, u64, u64, C.c_uint32, vp]
     lib.trew_synth_pair_ascii.argtypes = [u64, u64, u64, C.c_uint32, vp, vp]
     lib.trew_synth_pair_device.argtypes = [vp, u64, u64, u64, C.c_uint32, vp]
+    lib.trew_synth_long_lengths.argtypes = [u64, u64, u64, vp]
+    lib.trew_synth_long_ascii.argtypes = [u64, u64, u64, vp, vp]
+    lib.trew_synth_long_device.argtypes = [vp, u64, u64, u64, vp, vp]
     lib.trew_hip_malloc.argtypes = [vp, u64, C.POINTER(vp)]
     lib.trew_hip_free.argtypes = [vp, vp]
     lib.trew_hip_memcpy_h2d.argtypes = [vp, vp, vp, u64]
@@ -161,6 +165,25 @@ def synth_pair_ascii(seed, first_pair, n_pairs, read_len):
     st = np.arange(n_pairs, dtype=np.int64) * (read_len + 1)
     nd = st + read_len - 1
     return o1.tobytes(), o2.tobytes(), st, nd
+
+
+def synth_long_lengths(seed, first_read, n_reads):
+    lib = load()
+    lens = np.zeros(n_reads, dtype=np.uint32)
+    lib.trew_synth_long_lengths(seed, first_read, n_reads, lens.ctypes.data)
+    return lens
+
+
+def synth_long_ascii(seed, first_read, n_reads):
+    """Host side of the long-read generator: (buf, st, nd) with one '\\n' after each read."""
+    lib = load()
+    lens = synth_long_lengths(seed, first_read, n_reads).astype(np.int64)
+    st = np.zeros(n_reads, dtype=np.int64)
+    st[1:] = np.cumsum(lens[:-1] + 1)
+    out = np.zeros(int(st[-1] + lens[-1] + 1) if n_reads else 0, dtype=np.uint8)
+    st_u64 = np.ascontiguousarray(st, dtype=np.uint64)  # keep the array alive across the call
+    lib.trew_synth_long_ascii(seed, first_read, n_reads, st_u64.ctypes.data, out.ctypes.data)
+    return out.tobytes(), st, st + lens - 1
 
 
 class TrewHip:
@@ -290,6 +313,25 @@ class TrewHip:
     def synth_short_device(self, seed, first_read, n_reads, read_len, d_words):
         self._chk(self.lib.trew_synth_short_device(self.ctx, seed, first_read, n_reads, read_len, d_words),
                   "trew_synth_short_device")
+
+    def synth_long_device(self, seed, first_read, n_reads):
+        """Generate long reads on the device: returns (batch, device pointers to free)."""
+        lens = synth_long_lengths(seed, first_read, n_reads)
+        nw = 3 * ((lens.astype(np.int64) + 31) // 32)
+        offs = np.zeros(n_reads, dtype=np.int64)
+        offs[1:] = np.cumsum(nw[:-1])
+        total = int(offs[-1] + nw[-1]) if n_reads else 0
+        if total >= 2 ** 32:
+            raise TrewHipError("long batch exceeds 2^32 words")
+        offs32 = offs.astype(np.uint32)
+        d_words = self.malloc(total * 4 + 64)
+        d_offs = self.malloc(n_reads * 4)
+        d_lens = self.malloc(n_reads * 4)
+        self._chk(self.lib.trew_hip_memcpy_h2d(self.ctx, d_offs, offs32.ctypes.data, n_reads * 4), "h2d")
+        self._chk(self.lib.trew_hip_memcpy_h2d(self.ctx, d_lens, lens.ctypes.data, n_reads * 4), "h2d")
+        self._chk(self.lib.trew_synth_long_device(self.ctx, seed, first_read, n_reads, d_offs, d_words), "trew_synth_long_device")
+        b = Batch(d_words, total, d_offs, d_lens, 0, 0, n_reads, 1, int(lens.max()) if n_reads else 0)
+        return b, (d_words, d_offs, d_lens), int(lens.astype(np.int64).sum())
 
     def synth_pair_device(self, seed, first_pair, n_pairs, read_len, d_words):
         self._chk(self.lib.trew_synth_pair_device(self.ctx, seed, first_pair, n_pairs, read_len, d_words),

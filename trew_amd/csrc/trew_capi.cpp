@@ -674,6 +674,70 @@ extern "C" int trew_synth_pair_ascii(uint64_t seed, uint64_t first_pair, uint64_
     return 0;
 }
 
+// ---- long reads: quantile table of clip(lognormal(9.413, 0.7), 1000, 200000), host double math only
+static double inv_norm_cdf(double p) {  // Acklam's rational approximation (|rel err| < 1.2e-9)
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    const double pl = 0.02425;
+    if (p < pl) {
+        const double q = std::sqrt(-2 * std::log(p));
+        return (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    if (p > 1 - pl) return -inv_norm_cdf(1 - p);
+    const double q = p - 0.5, r = q * q;
+    return (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+}
+
+static const uint32_t *long_quantiles() {
+    static uint32_t table[trew_synth::kLongQuantiles];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < trew_synth::kLongQuantiles; i++) {
+            const double z = inv_norm_cdf((i + 0.5) / trew_synth::kLongQuantiles);
+            double len = std::exp(9.413 + 0.7 * z);
+            len = std::min(200000.0, std::max(1000.0, len));
+            table[i] = (uint32_t) len;
+        }
+        init = true;
+    }
+    return table;
+}
+
+extern "C" int trew_synth_long_lengths(uint64_t seed, uint64_t first_read, uint64_t n_reads, uint32_t *lengths) {
+    const uint32_t *qt = long_quantiles();
+    for (uint64_t r = 0; r < n_reads; r++) lengths[r] = trew_synth::long_class(seed, first_read + r, qt).len;
+    return 0;
+}
+
+extern "C" int trew_synth_long_ascii(uint64_t seed, uint64_t first_read, uint64_t n_reads, const uint64_t *byte_offsets, char *out) {
+    const uint32_t *qt = long_quantiles();
+    parallel_reads(n_reads, [=](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            const trew_synth::LongClass c = trew_synth::long_class(seed, first_read + r, qt);
+            char *o = out + byte_offsets[r];
+            for (uint32_t p = 0; p < c.len; p++) o[p] = trew_synth::base_char(trew_synth::long_base(seed, first_read + r, c, p));
+            o[c.len] = '\n';
+        }
+    });
+    return 0;
+}
+
+extern "C" int trew_synth_long_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
+                                      const uint32_t *d_offsets, uint32_t *d_words) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    uint32_t *d_qt = nullptr;
+    HIPCHK(ctx, hipMalloc((void **) &d_qt, trew_synth::kLongQuantiles * 4));
+    hipError_t e = hipMemcpy(d_qt, long_quantiles(), trew_synth::kLongQuantiles * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_synth_long(ctx->slots[0].stream, seed, first_read, n_reads, d_qt, d_offsets, d_words);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
+    (void) hipFree(d_qt);
+    HIPCHK(ctx, e);
+    return 0;
+}
+
 extern "C" int trew_synth_short_device(trew_hip_ctx *ctx, uint64_t seed, uint64_t first_read, uint64_t n_reads,
                                        uint32_t read_len, uint32_t *d_words) {
     if (!ctx) return -1;

@@ -1750,6 +1750,28 @@ __global__ void synth_pair_kernel(u64 seed, u64 first_pair, u64 n_pairs, u32 rea
     o[2] = nm;
 }
 
+// one block per long read; lengths[] / offsets[] (u32 word offsets) are precomputed on the host
+__global__ void synth_long_kernel(u64 seed, u64 first_read, u64 n_reads, const u32 *qtable, const u32 *offsets, u32 *words) {
+    const u64 r = blockIdx.x;
+    if (r >= n_reads) return;
+    const trew_synth::LongClass c = trew_synth::long_class(seed, first_read + r, qtable);
+    const u32 nw = (c.len + 31u) >> 5;
+    u32 *o = words + offsets[r];
+    for (u32 j = threadIdx.x; j < nw; j += blockDim.x) {
+        u32 lo = 0, hi = 0;
+        for (u32 i = 0; i < 32; i++) {
+            const u32 pos = 32u * j + i;
+            if (pos >= c.len) break;
+            const int b = trew_synth::long_base(seed, first_read + r, c, pos);
+            lo |= (u32) (b & 1) << i;
+            hi |= (u32) (b >> 1) << i;
+        }
+        o[3 * j + 0] = lo;
+        o[3 * j + 1] = hi;
+        o[3 * j + 2] = 0;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
 int pick_nw(u32 max_seg_len) {
     if (max_seg_len <= 95) return 3;
@@ -1849,6 +1871,12 @@ hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 le
     const u64 total = n * ((len + 31u) >> 5);
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_short_kernel, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, seed, first, n, len, d_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_long(hipStream_t st, u64 seed, u64 first, u64 n, const u32 *d_qtable, const u32 *d_offsets, u32 *d_words) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_long_kernel, dim3((u32) n), dim3(64), 0, st, seed, first, n, d_qtable, d_offsets, d_words);
     return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@ hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row
 hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n);
 hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
+hipError_t launch_synth_long(hipStream_t st, u64 seed, u64 first, u64 n, const u32 *d_qtable, const u32 *d_offsets, u32 *d_words);
 hipError_t launch_synth_pair(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
 
 }  // namespace trew

@@ -95,6 +95,43 @@ TREW_SYNTH_HD inline int pair_base(uint64_t seed, uint64_t frag, const ReadClass
     return b;
 }
 
+// ---- long reads (config 4): length drawn from a 1024-entry quantile table of
+// clip(lognormal(mu = 9.413, sigma = 0.7), 1000, 200000) (median ~12.2 kb, N50 ~20 kb); 5 % carry a
+// 2-6 kb (TTAGGG)n tail at the 3' end with 5 % substitutions (ONT-like); half of all reads are
+// reverse-complemented.  The table is computed once on the host (long_quantiles) and shared with the
+// device, so lengths never depend on device math.
+constexpr int kLongQuantiles = 1024;
+
+struct LongClass {
+    uint32_t len, tail_len, phase;
+    int rc;
+};
+
+TREW_SYNTH_HD inline LongClass long_class(uint64_t seed, uint64_t read, const uint32_t *qtable) {
+    const uint64_t h = key(seed, read, 0, 5);
+    LongClass c;
+    c.len = qtable[h % (uint64_t) kLongQuantiles];
+    const uint32_t u = (uint32_t) ((h >> 12) % 100u);
+    c.tail_len = u < 5u ? 2000u + (uint32_t) ((h >> 24) % 4001u) : 0u;
+    if (c.tail_len > c.len) c.tail_len = c.len;
+    c.phase = (uint32_t) ((h >> 40) % 6u);
+    c.rc = (int) ((h >> 50) & 1u);
+    return c;
+}
+
+TREW_SYNTH_HD inline int long_base(uint64_t seed, uint64_t read, const LongClass &c, uint32_t pos) {
+    const uint32_t q = c.rc ? (c.len - 1 - pos) : pos;
+    int b;
+    if (c.tail_len && q >= c.len - c.tail_len) {
+        b = motif_base(q + c.phase);
+        const uint64_t e = key(seed, read, q, 6);
+        if ((uint32_t) (e % 100u) < 5u) b = (b + 1 + (int) ((e >> 32) % 3u)) & 3;  // 5 % substitutions
+    } else {
+        b = (int) (key(seed, read, q, 7) & 3u);
+    }
+    return c.rc ? 3 - b : b;
+}
+
 TREW_SYNTH_HD inline char base_char(int b) { return b == 0 ? 'T' : b == 1 ? 'G' : b == 2 ? 'C' : b == 3 ? 'A' : 'N'; }
 
 }  // namespace trew_synth
