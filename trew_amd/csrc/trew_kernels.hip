@@ -670,7 +670,12 @@ __device__ __forceinline__ void wave_best(u32 best, WT best_seq, KStat<WT> &st) 
 // Fallback for segments with more than 64 runs: one item per window, class sizes
 // by an all-pairs LDS-broadcast compare.  vmask[] must hold the valid-window bits.
 template <typename WT>
-__attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, int k, KStat<WT> &st) {
+__attribute__((noinline)) __device__ KStat<WT> eval_k_windows(ExactSmem sm, int W, int k, u32 count) {
+    KStat<WT> st;  // returned by value: a reference parameter of a noinline function lives in scratch memory
+    st.count = count;
+    st.maxc = 0;
+    st.maxseq = 0;
+    st.pruned = false;
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     for (int r = 0; r < rounds; r++) {
@@ -713,10 +718,11 @@ __attribute__((noinline)) __device__ void eval_k_windows(ExactSmem sm, int W, in
     }
     wave_best<WT>(best, best_seq, st);
     st.n_items = (u32) W;
+    return st;
 }
 
 template <typename WT>
-__device__ void eval_runs(ExactSmem sm, int W, int k, KStat<WT> &st);
+__device__ KStat<WT> eval_runs(ExactSmem sm, int W, int k);
 
 // One k of the counting loop of k_mer_check / k_mer_target (kmer.cpp:2183-2216,
 // 1936-1967) on the segment staged in sm.  Lemma A: two
@@ -796,13 +802,17 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k
             return st;
         }
     }
-    eval_runs<WT>(sm, W, k, st);
-    return st;
+    return eval_runs<WT>(sm, W, k);
 }
 
 // Second half of eval_k: vmask[] / emask[] (+ one zero word) are in LDS, visible to the wave.
 template <typename WT>
-__attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, KStat<WT> &st) {
+__attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, int k) {
+    KStat<WT> st;
+    st.maxc = 0;
+    st.maxseq = 0;
+    st.n_items = 0;
+    st.pruned = false;
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
@@ -820,9 +830,9 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
     st.count = count;
     __syncthreads();
     if (R > 64) {
-        eval_k_windows<WT>(sm, W, k, st);
+        st = eval_k_windows<WT>(sm, W, k, count);
         __syncthreads();
-        return;
+        return st;
     }
     // one lane per run
     WT canon = ~(WT) 0;
@@ -866,6 +876,7 @@ __attribute__((noinline)) __device__ void eval_runs(ExactSmem sm, int W, int k, 
     wave_best<WT>(key, canon, st);
     st.n_items = R;
     __syncthreads();
+    return st;
 }
 
 // Wave-private count cache in LDS.  A few keys (the dominant motif's classes) receive an add from
@@ -1135,7 +1146,7 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
                     em[nq] = 0;
                 }
                 __syncthreads();
-                eval_runs<WT>(sm, W, k, st);
+                st = eval_runs<WT>(sm, W, k);
             }
         } else {
             st = eval_k<WT>(sm, L, k, need);
