@@ -483,3 +483,23 @@ def test_device_resident_uniform_batches(read_len, mn, mx):
         t.free(d)
     assert got == want
     assert sum(len(v) for v in want.values()) > 0
+
+
+def test_tiny_table_spills_but_stays_exact():
+    """A 4096-slot table (8 slots per partition) cannot hold the histograms of these reads: rows that
+    find their partition full go to the spill log and are merged by collect -- results stay exact."""
+    reads = edge_reads(11) + [s for s in mixed_segments(5, 1500, [150, 200, 300])]
+    want = O.run_short(O.OracleParams(), reads)
+    assert sum(len(v) for v in want.values()) > 4096  # more keys than slots: spilling is certain
+    with T.TrewHip(mode=T.MODE_SHORT, table_log2_slots=12, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22) as t:
+        for rep in range(2):  # second pass doubles every count, also through the spill path
+            t.submit_reads(reads)
+            t.wait()
+        got = t.collect()
+    assert got == {n: {k: 2 * c for k, c in want[n].items()} for n in want}
+    # and with 128-bit words
+    want = O.run_short(O.OracleParams(max_mer=64), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_mer=64, table_log2_slots=12, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22) as t:
+        t.submit_reads(reads)
+        t.wait()
+        assert t.collect() == want

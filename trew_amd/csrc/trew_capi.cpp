@@ -179,6 +179,11 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMalloc((void **) a, wb)) != hipSuccess) return bail("hipMalloc(wide table)", e);
             if ((e = hipMemset(*a, 0, wb)) != hipSuccess) return bail("hipMemset", e);
         }
+        // spill log: 1/16 of the table's slots, at least 64 k rows
+        ctx->wide.spill_cap = (u32) std::max<u64>(1ull << 16, ctx->table_slots >> 4);
+        if ((e = hipMalloc((void **) &ctx->wide.spill_rows, (size_t) ctx->wide.spill_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(spill log)", e);
+        if ((e = hipMalloc((void **) &ctx->wide.spill_n, 4)) != hipSuccess) return bail("hipMalloc(spill counter)", e);
+        if ((e = hipMemset(ctx->wide.spill_n, 0, 4)) != hipSuccess) return bail("hipMemset", e);
         DevWide *dw = nullptr;
         if ((e = hipMalloc((void **) &dw, sizeof(DevWide))) != hipSuccess) return bail("hipMalloc(wide descriptor)", e);
         if ((e = hipMemcpy(dw, &ctx->wide, sizeof(DevWide), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
@@ -240,6 +245,8 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->wide.wlo) (void) hipFree(ctx->wide.wlo);
     if (ctx->wide.whi) (void) hipFree(ctx->wide.whi);
     if (ctx->wide.wcount) (void) hipFree(ctx->wide.wcount);
+    if (ctx->wide.spill_rows) (void) hipFree(ctx->wide.spill_rows);
+    if (ctx->wide.spill_n) (void) hipFree(ctx->wide.spill_n);
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
@@ -388,7 +395,10 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     if (int rc = sync_all(ctx)) return rc;
     u32 ovf = 0;
     HIPCHK(ctx, hipMemcpy(&ovf, ctx->table.overflow, 4, hipMemcpyDeviceToHost));
-    if (ovf) return fail(ctx, "device count table overflow: raise table_log2_slots");
+    if (ovf) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
+    u32 n_spill = 0;
+    HIPCHK(ctx, hipMemcpy(&n_spill, ctx->wide.spill_n, 4, hipMemcpyDeviceToHost));
+    n_spill = std::min(n_spill, ctx->wide.spill_cap);
     // compact on the device, copy only the occupied rows (scratch buffers persist across calls)
     const u64 dcap = rows ? cap : 0;
     if (!ctx->d_collect_n) HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_n, 8));
@@ -407,9 +417,20 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_collect_n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     if (dcap && n) HIPCHK(ctx, hipMemcpy(rows, ctx->d_collect_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
+    if (n_spill) {
+        // rows that found their partition full: append them; duplicates are merged below
+        std::vector<trew_hip_row> sp(n_spill);
+        HIPCHK(ctx, hipMemcpy(sp.data(), ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
+        for (const auto &r : sp) {
+            if (table >= 0 && r.table != table) continue;
+            if (dcap && n < dcap) rows[n] = r;
+            n++;
+        }
+    }
     if (dcap && n && n <= dcap) {
-        // the wide-entry protocol may leave one key in two slots (see table_add_wide): counts are sums, merge them
-        bool any_wide = false;
+        // the wide-entry protocol may leave one key in two slots (see table_add_wide), spilled rows repeat
+        // keys: counts are sums, merge them
+        bool any_wide = n_spill != 0;
         for (u64 i = 0; i < n && !any_wide; i++) any_wide = rows[i].k > 32;
         if (any_wide) {
             std::sort(rows, rows + n, [](const trew_hip_row &a, const trew_hip_row &b) {
@@ -444,6 +465,7 @@ extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->wide.wlo, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
+    HIPCHK(ctx, hipMemset(ctx->wide.spill_n, 0, 4));
     return 0;
 }
 

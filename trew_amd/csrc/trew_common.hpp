@@ -50,9 +50,15 @@ struct DevTable {
 
 // wide entries (k in (32, 64], 128-bit words): tag / word halves / count per slot.  Kept behind a
 // pointer so that DevTable stays small enough to travel in registers.
+// spill_*: append-only log of (table, k, word, count) rows that found their table partition (or the
+// wide table) full; trew_hip_collect merges it, so a skewed key distribution degrades gracefully
+// instead of failing.  overflow (DevTable) is only raised when the log itself is full.
 struct DevWide {
     u64 *wtag, *wlo, *whi, *wcount;
     u32 wide_log2_slots;
+    u32 spill_cap;
+    trew_hip_row *spill_rows;
+    u32 *spill_n;
 };
 
 // per-read outputs of TREW_MODE_SEGMENT

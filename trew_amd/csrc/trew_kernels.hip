@@ -377,6 +377,23 @@ __device__ __forceinline__ u64 hash64(u64 x) {
     return x;
 }
 
+// the row's home (partition / wide table) is full: append it to the spill log
+__attribute__((noinline)) __device__ void table_spill(DevTable T, int table, int k, u64 lo, u64 hi, u64 cnt) {
+    const DevWide W = *T.wide;
+    const u32 at = atomicAdd(W.spill_n, 1u);
+    if (at < W.spill_cap) {
+        trew_hip_row r;
+        r.k = k;
+        r.table = table;
+        r.word_lo = lo;
+        r.word_hi = hi;
+        r.count = cnt;
+        W.spill_rows[at] = r;
+    } else {
+        atomicExch(T.overflow, 1u);
+    }
+}
+
 __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k, u64 word, u64 cnt) {
     if (T.log2_part_slots == 0xffffffffu) return;  // TREW_FLAG_DEBUG_NO_EMIT (timing experiments only)
     const u32 part = (u32) (word & ((1u << kTablePartBits) - 1u));
@@ -400,7 +417,7 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
             return;
         }
     }
-    atomicExch(T.overflow, 1u);
+    table_spill(T, table, k, word, 0ull, cnt);
 }
 
 // Wide entries (k in (32, 64], 128-bit words).  Slot = {tag, word_lo, word_hi, count};
@@ -441,7 +458,7 @@ __attribute__((noinline)) __device__ void table_add_wide(DevTable T0, int table,
             }
         }
     }
-    atomicExch(T0.overflow, 1u);
+    table_spill(T0, table, k, lo, hi, cnt);
 }
 
 __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 word, u64 cnt) {
