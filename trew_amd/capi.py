@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrew_hip.so")
+LIB_PATH = os.environ.get("TREW_HIP_LIB") or os.path.join(_HERE, "lib", "libtrew_hip.so")  # TREW_HIP_LIB: alternative build (tools/phase_profile.py)
 
 MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
 FLAG_NO_FILTER = 1

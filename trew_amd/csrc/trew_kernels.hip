@@ -270,7 +270,139 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 }
 
 
+// ------------------------------------------------------------------ prefilter, uniform-geometry fast path
+// Batches of equal-length reads (trew_hip_batch.uniform_length, the usual Illumina case) have the same
+// segment geometry for every unit, so everything that depends only on (segment length, k) is wave-uniform:
+// COUNT = L-k+1, the window mask of the last word and the pass threshold live in SGPRs / an LDS table
+// instead of being recomputed per lane.  Reads with an N inside a segment do not fit that model (their
+// COUNT differs); they are set aside in LDS and go through the general filter_segment, 256 at a time.
+// Per k and word this leaves 2 alignbit + 2 xor + 1 and + 3 bcnt -- the kernel is VALU-issue bound
+// (every wave64 VALU instruction occupies its SIMD16 for 4 cycles), so instruction count is time.
+// The verdicts of the 64 lanes are kept as wave masks in SGPRs (hasm: lanes that already own a
+// candidate, the return value: lanes passing at this k), so the bookkeeping per k is scalar work.
+// thr_row[k-1] = {ithr, jthr}: (float) m > (float) COUNT * lowf  <=>  m >= ithr = floor((float) COUNT * lowf) + 1,
+// and bucket 00 = COUNT - t reaches ithr  <=>  t <= jthr = COUNT - ithr.
+template <int NW, int WS, int NWW>
+__device__ __forceinline__ u64 filter_k_uni(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int L, int k,
+                                            const int2 *thr_row, u64 hasm) {
+    const u32 bs = (u32) k & 31u;
+    const int W = L - k + 1;                  // COUNT, wave-uniform
+    const int lastbits = W - 32 * (NWW - 1);  // windows in word NWW-1: [0, 32) by construction of FilterRangeUni
+    const u32 wm = lastbits >= 32 ? 0xffffffffu : (lastbits <= 0 ? 0u : ((1u << lastbits) - 1u));
+    u32 F1[NWW], F2[NWW];
+    u32 c1x = 0, cx1 = 0, c11 = 0;
+#pragma unroll
+    for (int j = 0; j < NWW; j++) {
+        F1[j] = P1[j] ^ shr_word<NW, WS>(P1, j, bs);
+        F2[j] = P2[j] ^ shr_word<NW, WS>(P2, j, bs);
+        if (j == NWW - 1) {
+            F1[j] &= wm;
+            F2[j] &= wm;
+            // keep the masked words as values: otherwise the compiler re-derives them inside every
+            // 3-input bit op below and spends two extra xors per k
+            asm volatile("" : "+v"(F1[j]), "+v"(F2[j]));
+        }
+        c1x += __popc(F1[j]);
+        cx1 += __popc(F2[j]);
+        c11 += __popc(F1[j] & F2[j]);
+    }
+    const int2 th = thr_row[k - 1];
+    const u32 c10 = c1x - c11, c01 = cx1 - c11;
+    const u32 m3 = max(max(c10, c01), c11);
+    const int t = (int) (c1x + c01);  // COUNT - c00
+    const u64 p4 = __ballot(m3 >= (u32) th.x) | __ballot(t <= th.y);  // two compares straight into SGPR masks
+    u64 pm = p4;
+    if (p4 & ~hasm) {  // third parity, as in filter_k: only for a lane's first candidate
+        u32 c001 = 0, c010 = 0, c011 = 0, c100 = 0, c101 = 0, c110 = 0, c111 = 0;
+#pragma unroll
+        for (int j = 0; j < NWW; j++) {
+            const u32 F3 = P3[j] ^ shr_word<NW, WS>(P3, j, bs);
+            const u32 v = j == NWW - 1 ? wm : 0xffffffffu;
+            const u32 a11 = F1[j] & F2[j], a10 = F1[j] & ~F2[j], a01 = ~F1[j] & F2[j], a00 = v & ~(F1[j] | F2[j]);
+            const u32 b111 = a11 & F3, b101 = a10 & F3, b011 = a01 & F3, b001 = a00 & F3;
+            c111 += __popc(b111);
+            c110 += __popc(a11 ^ b111);
+            c101 += __popc(b101);
+            c100 += __popc(a10 ^ b101);
+            c011 += __popc(b011);
+            c010 += __popc(a01 ^ b011);
+            c001 += __popc(b001);
+        }
+        const u32 c000 = (u32) W - c001 - c010 - c011 - c100 - c101 - c110 - c111;
+        const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
+        const u64 p8 = __ballot(m8 >= (u32) th.x);
+        pm = (p4 & hasm) | (p8 & ~hasm);
+    }
+    return pm;
+}
+
+// what one segment's k loop accumulates
+struct UniVerdict {
+    u64 hasm;   // wave mask: lanes with a candidate at any k of the loop so far
+    u64 flagm;  // wave mask: lanes with a candidate inside the segment's own [kmin, kmax]
+    u32 clo, chi;  // this lane's candidate mask (only maintained when `dbg`)
+};
+
+// as FilterRange, with the word count taken from the segment's own (uniform) length
+template <int NW, int WS, int NWW>
+struct FilterRangeUni {
+    static __device__ __forceinline__ void run(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int klo, int khi, int L,
+                                               int kmin, int kmax, const int2 *thr_row, bool dbg, UniVerdict &vd) {
+        int a = L + 2 - 32 * NWW, b = L + 1 - 32 * (NWW - 1);
+        if (NWW == NW) a = klo;
+        a = a < klo ? klo : a;
+        b = b > khi ? khi : b;
+        for (int k = a; k <= b; k++) {
+            const u64 pm = filter_k_uni<NW, WS, NWW>(P1, P2, P3, L, k, thr_row, vd.hasm);
+            vd.hasm |= pm;
+            if (k >= kmin && k <= kmax) vd.flagm |= pm;
+            if (dbg) {  // wave-uniform: trew_hip_filter_masks wants the per-lane masks
+                const bool mine = (pm >> lane_id()) & 1ull;
+                if (k <= 32)
+                    vd.clo |= mine ? (1u << ((k - 1) & 31)) : 0u;
+                else
+                    vd.chi |= mine ? (1u << ((k - 33) & 31)) : 0u;
+            }
+        }
+        FilterRangeUni<NW, WS, NWW - 1>::run(P1, P2, P3, klo, khi, L, kmin, kmax, thr_row, dbg, vd);
+    }
+};
+template <int NW, int WS>
+struct FilterRangeUni<NW, WS, 0> {
+    static __device__ __forceinline__ void run(const u32 (&)[NW], const u32 (&)[NW], const u32 (&)[NW], int, int, int, int, int, const int2 *,
+                                               bool, UniVerdict &) {}
+};
+
+// N-free segment of wave-uniform length L (same verdicts as filter_segment): vd.flagm = lanes with a
+// candidate k, vd.clo/chi = the lane's candidate mask when dbg
+template <int NW>
+__device__ __forceinline__ void filter_segment_uni(const u32 (&lo)[NW], const u32 (&hi)[NW], int L, int kmin, int kmax, int gmin, int gmax,
+                                                   const int2 *thr_row, bool dbg, UniVerdict &vd) {
+    u32 P1[NW], P2[NW], P3[NW];
+    {
+        u32 f1[NW], f2[NW], f3[NW];
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const int bits = L - 32 * j;
+            const u32 lm = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+            f1[j] = lo[j] & lm;
+            f2[j] = hi[j] & lm;
+            f3[j] = f1[j] & f2[j];
+        }
+        prefix_parity<NW>(f1, P1);
+        prefix_parity<NW>(f2, P2);
+        prefix_parity<NW>(f3, P3);
+    }
+    vd.hasm = vd.flagm = 0;
+    vd.clo = vd.chi = 0;
+    const int g31 = gmax < 31 ? gmax : 31;
+    FilterRangeUni<NW, 0, NW>::run(P1, P2, P3, gmin, g31, L, kmin, kmax, thr_row, dbg, vd);
+    FilterRangeUni<NW, 1, NW>::run(P1, P2, P3, gmin > 32 ? gmin : 32, gmax < 63 ? gmax : 63, L, kmin, kmax, thr_row, dbg, vd);
+    FilterRangeUni<NW, 2, NW>::run(P1, P2, P3, gmin > 64 ? gmin : 64, gmax, L, kmin, kmax, thr_row, dbg, vd);
+}
+
 constexpr u32 kStage = 1024;  // unit indices a block stages in LDS before one global append
+constexpr u32 kDefer = 512;   // units set aside by the fast path (drained 256 at a time)
 
 // Persistent blocks, grid-stride over the reads.  Survivors are staged in LDS and appended to
 // the worklist with ONE global atomic per flush: a per-wave atomic on the single worklist
@@ -283,7 +415,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
     __shared__ u32 stage_n, flush_base;
     if (threadIdx.x == 0) stage_n = 0;
     __syncthreads();
-    auto flush = [&]() {  // block-uniform
+    auto flush = [&]() __attribute__((always_inline)) {  // block-uniform
         const u32 n = stage_n;
         if (n) {
             if (threadIdx.x == 0) flush_base = atomicAdd(wl_count, n);
@@ -296,10 +428,24 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
         }
         __syncthreads();
     };
+    // wave-aggregated append of the flagged units to the block's LDS stage (block-uniform call)
+    auto append = [&](bool flag, u32 unit) __attribute__((always_inline)) {
+        const u64 bal = __ballot(flag);
+        if (bal) {
+            const u32 lane = lane_id();
+            const int leader = __ffsll((long long) bal) - 1;
+            u32 sb = 0;
+            if ((int) lane == leader) sb = atomicAdd(&stage_n, (u32) __popcll(bal));
+            sb = __shfl(sb, leader);
+            if (flag) stage[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = unit;  // < kStage: flushed below when > kStage-256
+        }
+        __syncthreads();
+        if (stage_n > kStage - 256u) flush();
+    };
     const int nslots = mode_slots(P.mode);
-    for (u64 base = (u64) blockIdx.x * blockDim.x; base < B.n_units; base += (u64) gridDim.x * blockDim.x) {
-        const u64 unit = base + threadIdx.x;
-        const bool active = unit < B.n_units;
+    const int gmax_run = (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer;
+    // general path: any read length, N anywhere
+    auto general = [&](u64 unit, bool active) __attribute__((always_inline)) -> u64 {
         ReadRef rd[2];
         rd[0].w = B.words;
         rd[0].len = 0;
@@ -336,8 +482,7 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
                     if (P.flags & TREW_FLAG_NO_FILTER)
                         m = all_k_mask(sg.kmin, sg.kmax);
                     else
-                        m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer,
-                                               (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer, max_seg, P.lowf);
+                        m = filter_segment<NW>(lo, hi, nm, ok ? (int) sg.len : 0, sg.kmin, sg.kmax, P.min_mer, gmax_run, max_seg, P.lowf);
                     mask = ok ? m : 0ull;
                 }
                 // a segment too long for this instantiation must never be dropped silently
@@ -346,19 +491,112 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
                 if (dbg_masks && active && slot < dbg_slots) dbg_masks[unit * (u64) dbg_slots + slot] = mask;
             }
         }
-        // wave-aggregated append to the block's LDS stage
-        const bool flag = active && any != 0;
-        const u64 bal = __ballot(flag);
-        if (bal) {
-            const u32 lane = lane_id();
-            const int leader = __ffsll((long long) bal) - 1;
-            u32 sb = 0;
-            if ((int) lane == leader) sb = atomicAdd(&stage_n, (u32) __popcll(bal));
-            sb = __shfl(sb, leader);
-            if (flag) stage[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = (u32) unit;  // < kStage: flushed below when > kStage-256
+        return any;
+    };
+
+    // One loop for both kinds of batch, so that the (large) general path is instantiated once:
+    // every round the block takes 256 fresh units; the fast path judges the N-free ones on the spot
+    // and sets the others aside, a batch without uniform geometry sets all of them aside; whenever
+    // 256 units are waiting (or the input is exhausted) the general path drains them.
+    __shared__ u32 defer[kDefer];
+    __shared__ u32 defer_n;
+    __shared__ int2 thr_tab[kMaxSlots][64];
+    const u32 UL = B.uniform_length;
+    const bool uni = NW <= 5 && UL != 0 && P.mode != TREW_MODE_LONG && !(P.flags & TREW_FLAG_NO_FILTER);
+    if (uni) {
+        for (u32 i = threadIdx.x; i < (u32) kMaxSlots * 64u; i += blockDim.x) {
+            const int slot = (int) (i >> 6), k = (int) (i & 63u) + 1;
+            const Segment sg = get_segment(P.mode, slot, UL, UL, P.min_mer, P.max_mer, P.slice_len);
+            const int W = (int) sg.len - k + 1;
+            int2 th;
+            th.x = 0x7fffffff;  // nothing passes
+            th.y = -1;
+            if (slot < nslots && sg.valid && W > 0) {
+                th.x = (int) floorf((float) W * P.lowf) + 1;
+                th.y = W - th.x;
+            }
+            thr_tab[slot][k - 1] = th;
         }
-        __syncthreads();
-        if (stage_n > kStage - 256u) flush();
+    }
+    if (threadIdx.x == 0) defer_n = 0;
+    __syncthreads();
+    u64 base = (u64) blockIdx.x * blockDim.x;
+    for (;;) {
+        const bool more = base < B.n_units;  // block-uniform
+        if (more) {
+            const u64 unit = base + threadIdx.x;
+            const bool active = unit < B.n_units;
+            base += (u64) gridDim.x * blockDim.x;
+            u64 any = 0;
+            bool dfr = active;
+            if constexpr (NW <= 5) {
+                if (uni) {
+                    ReadRef rd[2];
+                    rd[0].w = B.words;
+                    rd[0].len = 0;
+                    rd[0].nw = 0;
+                    rd[1] = rd[0];
+                    if (active) {
+                        if (P.mode == TREW_MODE_PAIR) {
+                            rd[0] = get_read(B, 2 * unit);
+                            rd[1] = get_read(B, 2 * unit + 1);
+                        } else {
+                            rd[0] = get_read(B, unit);
+                        }
+                    }
+                    dfr = false;
+                    for (int slot = 0; slot < nslots; slot++) {  // wave-uniform geometry: no need to unroll
+                        const Segment sg = get_segment(P.mode, slot, UL, UL, P.min_mer, P.max_mer, P.slice_len);
+                        if (!sg.valid) continue;
+                        if (sg.len > (u32) (32 * NW - 1)) {  // too long for this instantiation: the general path keeps every k
+                            dfr = dfr || active;
+                            continue;
+                        }
+                        u32 lo[NW], hi[NW], nm[NW];
+                        const ReadRef r = sg.mate ? rd[1] : rd[0];
+                        load_planes<NW>(r, sg.start, lo, hi, nm);
+                        u32 anyn = 0;
+#pragma unroll
+                        for (int j = 0; j < NW; j++) {
+                            const int bits = (int) sg.len - 32 * j;
+                            const u32 lm = bits >= 32 ? 0xffffffffu : (bits <= 0 ? 0u : ((1u << bits) - 1u));
+                            anyn |= nm[j] & lm;
+                        }
+                        UniVerdict vd;
+                        filter_segment_uni<NW>(lo, hi, (int) sg.len, sg.kmin, sg.kmax, P.min_mer, gmax_run, thr_tab[slot], dbg_masks != nullptr, vd);
+                        dfr = dfr || (active && anyn != 0);
+                        any |= (vd.flagm >> lane_id()) & 1ull;
+                        if (dbg_masks && active && anyn == 0 && slot < dbg_slots)
+                            dbg_masks[unit * (u64) dbg_slots + slot] = ((((u64) vd.chi) << 32) | vd.clo) & all_k_mask(sg.kmin, sg.kmax);
+                    }
+                }
+            }
+            {
+                const u64 bal = __ballot(dfr);
+                if (bal) {
+                    const u32 lane = lane_id();
+                    const int leader = __ffsll((long long) bal) - 1;
+                    u32 sb = 0;
+                    if ((int) lane == leader) sb = atomicAdd(&defer_n, (u32) __popcll(bal));
+                    sb = __shfl(sb, leader);
+                    if (dfr) defer[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = (u32) unit;  // < kDefer: drained below at 256
+                }
+            }
+            append(active && !dfr && any != 0, (u32) unit);  // syncs the block
+        }
+        const u32 dn = defer_n;  // block-uniform: every add happened before the last barrier
+        if (dn >= 256u || (!more && dn > 0u)) {
+            const u32 take = dn < 256u ? dn : 256u;
+            const u32 at = dn - take;
+            const bool active2 = threadIdx.x < take;
+            const u32 unit2 = active2 ? defer[at + threadIdx.x] : 0u;
+            __syncthreads();
+            if (threadIdx.x == 0) defer_n = at;
+            const u64 any2 = general(unit2, active2);
+            append(active2 && any2 != 0, unit2);
+        } else if (!more) {
+            break;
+        }
     }
     flush();
 }
@@ -504,6 +742,31 @@ __device__ __forceinline__ unsigned char *lds0() {
     extern __shared__ __attribute__((aligned(16))) unsigned char trew_lds[];
     return trew_lds;
 }
+// Phase profile (tools/phase_profile.py, built with -DTREW_PHASE_PROFILE only): lane 0 of each wave
+// accumulates s_memtime deltas per phase in LDS and adds them to g_phase when the wave retires.
+#ifdef TREW_PHASE_PROFILE
+__device__ unsigned long long g_phase[32];
+__device__ __forceinline__ unsigned long long *ph_lds() {
+    __shared__ unsigned long long ph[32];
+    return ph;
+}
+#define PH_T0(v) const unsigned long long v = (unsigned long long) clock64()
+#define PH_ADD(i, v)                                                                  \
+    do {                                                                              \
+        if (lane_id() == 0) ph_lds()[i] += (unsigned long long) clock64() - (v);      \
+    } while (0)
+#define PH_CNT(i, c)                                   \
+    do {                                               \
+        if (lane_id() == 0) ph_lds()[i] += (c);        \
+    } while (0)
+#else
+#define PH_T0(v)
+#define PH_ADD(i, v)
+#define PH_CNT(i, c)
+#endif
+enum { PH_TOTAL = 0, PH_STAGE, PH_LOADSEG, PH_BOUNDS, PH_DECIDE, PH_RUNS, PH_WINDOWS, PH_RECORD_EVAL, PH_EMIT, PH_FLUSH, PH_EVALK_A,
+       PH_N_READS = 16, PH_N_RUNS_CALLS, PH_N_WINDOWS_CALLS, PH_N_RECORD, PH_N_RUNS_TOTAL, PH_N_K5 };
+
 __device__ __forceinline__ u64 *sm_seq(ExactSmem sm) { return (u64 *) lds0(); }
 __device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_seq(sm) + (sm.cap / 32 + 2); }
 __device__ __forceinline__ u64 *sm_emask(ExactSmem sm) { return sm_vmask(sm) + (sm.cap / 64 + 2); }
@@ -541,6 +804,7 @@ __device__ ReadRef stage_read(ExactSmem sm, const ReadRef &rd, int mate) {
 }
 
 __attribute__((noinline)) __device__ void load_segment(ExactSmem sm, const ReadRef &rd, u32 s, u32 L) {
+    PH_T0(t_ph);
     __syncthreads();
     const u32 nwords = (L + 31u) >> 5;
     const u32 segwords = sm.cap / 32 + 2;
@@ -560,6 +824,7 @@ __attribute__((noinline)) __device__ void load_segment(ExactSmem sm, const ReadR
         sm_nmask(sm)[lane] = nmv;
     }
     __syncthreads();
+    PH_ADD(PH_LOADSEG, t_ph);
 }
 
 
@@ -689,6 +954,8 @@ __device__ __forceinline__ void wave_best(u32 best, WT best_seq, KStat<WT> &st) 
 template <typename WT>
 __attribute__((noinline)) __device__ KStat<WT> eval_k_windows(ExactSmem sm, int W, int k, u32 count) {
     KStat<WT> st;  // returned by value: a reference parameter of a noinline function lives in scratch memory
+    PH_T0(t_ph);
+    PH_CNT(PH_N_WINDOWS_CALLS, 1);
     st.count = count;
     st.maxc = 0;
     st.maxseq = 0;
@@ -735,6 +1002,7 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k_windows(ExactSmem sm, int 
     }
     wave_best<WT>(best, best_seq, st);
     st.n_items = (u32) W;
+    PH_ADD(PH_WINDOWS, t_ph);
     return st;
 }
 
@@ -764,6 +1032,7 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k
     st.pruned = false;
     const int W = L - k + 1;
     if (W <= 0) return st;
+    PH_T0(t_ph);
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     WT m5 = (WT) 0x5555555555555555ull;
@@ -819,6 +1088,7 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k
             return st;
         }
     }
+    PH_ADD(PH_EVALK_A, t_ph);
     return eval_runs<WT>(sm, W, k);
 }
 
@@ -832,6 +1102,9 @@ __attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, in
     st.pruned = false;
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
+    PH_T0(t_ph);
+    PH_CNT(PH_N_RUNS_CALLS, 1);
+    PH_CNT(PH_N_K5, k == 5 ? 1 : 0);
     // run starts: valid_i && !(valid_{i-1} && eq_{i-1}); compacted into start[]
     u32 R = 0, count = 0;
     u64 carry = 0;
@@ -849,6 +1122,7 @@ __attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, in
     if (R > 64) {
         st = eval_k_windows<WT>(sm, W, k, count);
         __syncthreads();
+        PH_ADD(PH_RUNS, t_ph);
         return st;
     }
     // one lane per run
@@ -893,6 +1167,8 @@ __attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, in
     wave_best<WT>(key, canon, st);
     st.n_items = R;
     __syncthreads();
+    PH_CNT(PH_N_RUNS_TOTAL, R);
+    PH_ADD(PH_RUNS, t_ph);
     return st;
 }
 
@@ -955,6 +1231,7 @@ __device__ void cache_flush(ExactSmem sm, DevTable T) {
 template <typename WT>
 __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
     const u32 lane = lane_id();
+    PH_T0(t_ph);
     for (u32 i = lane; i < n_items; i += 64) {
         const u32 c = sm_cnt(sm)[i];
         if (c) {
@@ -966,6 +1243,7 @@ __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n
             for (u32 tm = table_mask; tm; tm &= tm - 1) cached_add(sm, T, __ffs((int) tm) - 1, k, w, c);
         }
     }
+    PH_ADD(PH_EMIT, t_ph);
 }
 
 // per-lane variable right shift of a multiword mask by off in [0, 63]
@@ -991,6 +1269,7 @@ struct LaneMasks {
 
 template <int NW>
 __device__ __forceinline__ void lane_bounds(const ReadRef &rd, u32 s, int L, int gmin, int gmax, LaneMasks<NW> &out) {
+    PH_T0(t_ph);
     u32 lo[NW], hi[NW], nm[NW];
     load_planes<NW>(rd, s, lo, hi, nm);  // every lane reads the same (LDS-staged) words
     u32 v1[NW], P1[NW], P2[NW], P3[NW];
@@ -1080,6 +1359,7 @@ __device__ __forceinline__ void lane_bounds(const ReadRef &rd, u32 s, int L, int
     const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
     // k = 64 is not bounded here (shift amounts stay below 64): never prune it
     out.ub = (k > gmax || k >= 64 || count == 0) ? ((k >= 64 && k <= gmax) ? 2.0 : 0.0) : (double) m8 / (double) count;
+    PH_ADD(PH_BOUNDS, t_ph);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -1108,6 +1388,7 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     constexpr bool HAVE_UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
     Decision<WT> d;
+    PH_T0(t_ph);
     d.kh = d.kl = 0;
     d.sh = d.sl = 0;
     double tf_low = 0.0, tf_high = 0.0;
@@ -1115,24 +1396,33 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     // never accepted and never moves the running frequency (kmer.cpp:2225-2236).
     u64 closed_low = 0, closed_high = 0;
     u64 todo = cand & all_k_mask(kmin, kmax);
-    if (HAVE_UB) {
-        // every threshold is >= LOW_BASELINE: one ballot drops all k whose bound is already below it
-        const u64 alive = __ballot(M.ub >= P.low);  // lane l <-> k = MIN_MER + l
-        todo &= P.min_mer > 1 ? (alive << (P.min_mer - 1)) : alive;
-    }
-    while (todo) {
-        const int k = __ffsll((long long) todo);  // bit k-1 -> k, ascending
+    // lane l <-> k = MIN_MER + l (as in lane_bounds); only used when HAVE_UB
+    const int kl = P.min_mer + (int) lane_id();
+    const u32 klb = (u32) (kl - 1) & 63u;
+    for (;;) {
+        const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
+        const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
+        int k;
+        if (HAVE_UB) {
+            // Next k the scalar loop would evaluate, found for all k at once: k still open in one of
+            // the two selection loops and its bound reaches the smallest threshold it has to meet
+            // (MAX <= maxbucket and IEEE division is monotone in the numerator: f <= bound < need
+            // can never be accepted).  Thresholds only move when a k is accepted, after which the
+            // eligibility is recomputed, so skipping is equivalent to the k-by-k walk.
+            const bool lo_l = !((closed_low >> klb) & 1ull), hi_l = !((closed_high >> klb) & 1ull);
+            const double need_l = lo_l ? (hi_l ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
+            const u64 el = __ballot(kl <= 64 && (lo_l || hi_l) && M.ub >= need_l);
+            todo &= P.min_mer > 1 ? (el << (P.min_mer - 1)) : el;
+        }
+        if (!todo) break;
+        k = __ffsll((long long) todo);  // bit k-1 -> k, ascending
         todo &= todo - 1;
         const bool lo_open = !((closed_low >> (k - 1)) & 1ull), hi_open = !((closed_high >> (k - 1)) & 1ull);
         if (!lo_open && !hi_open) continue;
-        const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
-        const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
         KStat<WT> st;
         if (HAVE_UB) {
             const int src = k - P.min_mer;
-            // MAX <= maxbucket and IEEE division is monotone in the numerator: f <= bound < need
-            if (readlane_f64(M.ub, src) < need) continue;
             // the window masks of this k were computed bit-parallel by lane `src`: fetch them
             // instead of walking the windows (phase A of eval_k)
             st.count = st.maxc = st.n_items = 0;
@@ -1184,6 +1474,7 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
             d.sh = st.maxseq;
         }
     }
+    PH_ADD(PH_DECIDE, t_ph);
     return d;
 }
 
@@ -1191,14 +1482,20 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
 template <typename WT>
 __device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
     if (k <= 0 || table_mask == 0) return;
+    PH_T0(t_ph);
+    PH_CNT(PH_N_RECORD, 1);
     const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
+    PH_ADD(PH_RECORD_EVAL, t_ph);
     emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
 // k_mer_target, kmer.cpp:1894-2017, on the staged whole read
 template <typename WT>
 __device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
+    PH_T0(t_ph);
+    PH_CNT(PH_N_RECORD, 1);
     const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
+    PH_ADD(PH_RECORD_EVAL, t_ph);
     if (st.count == 0) return;
     const double f = is_homopolymer<WT>(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
     u32 tm = 0;
@@ -1590,6 +1887,11 @@ __global__ __launch_bounds__(64, (MODE == TREW_MODE_PAIR ? 4 : 6)) void exact_ke
     sm.rawwords = rawwords;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
+#ifdef TREW_PHASE_PROFILE
+    if (lane_id() < 32) ph_lds()[lane_id()] = 0;
+    __syncthreads();
+#endif
+    PH_T0(t_total);
     cache_clear(sm);
     // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from device counters
     // instead of a static stride.  One returning atomic on a single word saturates at ~88
@@ -1606,6 +1908,7 @@ __global__ __launch_bounds__(64, (MODE == TREW_MODE_PAIR ? 4 : 6)) void exact_ke
     for (u32 attempt = 0; attempt < kShards; attempt++) {
         const u32 sh = (my + attempt) & (kShards - 1);
         for (;;) {
+            PH_T0(t_stage);
             u32 c = 0;
             if (lane == 0) c = atomicAdd(&heads[sh * kHeadStride], 1u);
             c = rfl(c);
@@ -1650,6 +1953,8 @@ __global__ __launch_bounds__(64, (MODE == TREW_MODE_PAIR ? 4 : 6)) void exact_ke
                     }
                 }
                 __syncthreads();
+                PH_ADD(PH_STAGE, t_stage);
+                PH_CNT(PH_N_READS, nit);
                 for (u32 t = 0; t < nit; t++) {  // not unrolled: one copy of the driver
                     ReadRef rd;
                     rd.len = rfl(meta[5 * t + 0]);
@@ -1677,8 +1982,28 @@ __global__ __launch_bounds__(64, (MODE == TREW_MODE_PAIR ? 4 : 6)) void exact_ke
             }
         }
     }
-    cache_flush(sm, T);
+    {
+        PH_T0(t_flush);
+        cache_flush(sm, T);
+        PH_ADD(PH_FLUSH, t_flush);
+    }
+    PH_ADD(PH_TOTAL, t_total);
+#ifdef TREW_PHASE_PROFILE
+    __syncthreads();
+    if (lane_id() < 32) atomicAdd(&g_phase[lane_id()], ph_lds()[lane_id()]);
+#endif
 }
+
+#ifdef TREW_PHASE_PROFILE
+extern "C" int trew_debug_phases(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------ table maintenance
 __global__ void table_add_rows_kernel(DevTable T, const trew_hip_row *rows, u64 n) {
