@@ -48,6 +48,32 @@ __device__ __forceinline__ u64 rfl64(u64 v) {
     return ((u64) hi << 32) | lo;
 }
 
+// Arguments of a noinline device function arrive in VGPRs, so the compiler has to treat them as
+// divergent: loops run on exec masks and address arithmetic on the VALU.  The values below are
+// wave-uniform by construction; re-reading them through readfirstlane moves them (and everything
+// derived from them) to the scalar unit.
+__device__ __forceinline__ int rfl_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename Tp>
+__device__ __forceinline__ Tp *rfl_ptr(Tp *p) {
+    return (Tp *) rfl64((u64) p);
+}
+__device__ __forceinline__ double rfl_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// wave max of a u32 (0 for idle lanes), every lane gets the result.  DPP row shifts and row
+// broadcasts: 6 VALU instructions instead of 6 LDS-crossbar round trips (ds_bpermute).
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+    // max is idempotent, so overlapping shifts are fine: after row_shr 1,2,4,8 lane 15 of each row holds the row's max
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true));  // row_shr:1
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true));  // row_shr:2
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true));  // row_shr:4
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true));  // row_shr:8
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1 and 3
+    v = max(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2 and 3
+    return (u32) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 struct ReadRef {
     const u32 *w;  // first triple
     u32 len;       // bases
@@ -284,11 +310,11 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 // and bucket 00 = COUNT - t reaches ithr  <=>  t <= jthr = COUNT - ithr.
 template <int NW, int WS, int NWW>
 __device__ __forceinline__ u64 filter_k_uni(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int L, int k,
-                                            const int2 *thr_row, u64 hasm) {
+                                            const int2 th, u64 hasm) {
     const u32 bs = (u32) k & 31u;
     const int W = L - k + 1;                  // COUNT, wave-uniform
     const int lastbits = W - 32 * (NWW - 1);  // windows in word NWW-1: [0, 32) by construction of FilterRangeUni
-    const u32 wm = lastbits >= 32 ? 0xffffffffu : (lastbits <= 0 ? 0u : ((1u << lastbits) - 1u));
+    const u32 wm = (1u << (lastbits & 31)) - 1u;
     u32 F1[NWW], F2[NWW];
     u32 c1x = 0, cx1 = 0, c11 = 0;
 #pragma unroll
@@ -306,7 +332,6 @@ __device__ __forceinline__ u64 filter_k_uni(const u32 (&P1)[NW], const u32 (&P2)
         cx1 += __popc(F2[j]);
         c11 += __popc(F1[j] & F2[j]);
     }
-    const int2 th = thr_row[k - 1];
     const u32 c10 = c1x - c11, c01 = cx1 - c11;
     const u32 m3 = max(max(c10, c01), c11);
     const int t = (int) (c1x + c01);  // COUNT - c00
@@ -343,8 +368,11 @@ struct UniVerdict {
     u32 clo, chi;  // this lane's candidate mask (only maintained when `dbg`)
 };
 
-// as FilterRange, with the word count taken from the segment's own (uniform) length
-template <int NW, int WS, int NWW>
+// as FilterRange, with the word count taken from the segment's own (uniform) length.
+// SLOW: some k of the loop lie outside the segment's [kmin, kmax], or the per-lane masks are wanted
+// (trew_hip_filter_masks); otherwise flagm is simply hasm after the loop and the per-k bookkeeping
+// is one scalar OR.  The thresholds of the next k are fetched from LDS one iteration ahead.
+template <int NW, int WS, int NWW, bool SLOW>
 struct FilterRangeUni {
     static __device__ __forceinline__ void run(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int klo, int khi, int L,
                                                int kmin, int kmax, const int2 *thr_row, bool dbg, UniVerdict &vd) {
@@ -352,23 +380,30 @@ struct FilterRangeUni {
         if (NWW == NW) a = klo;
         a = a < klo ? klo : a;
         b = b > khi ? khi : b;
-        for (int k = a; k <= b; k++) {
-            const u64 pm = filter_k_uni<NW, WS, NWW>(P1, P2, P3, L, k, thr_row, vd.hasm);
-            vd.hasm |= pm;
-            if (k >= kmin && k <= kmax) vd.flagm |= pm;
-            if (dbg) {  // wave-uniform: trew_hip_filter_masks wants the per-lane masks
-                const bool mine = (pm >> lane_id()) & 1ull;
-                if (k <= 32)
-                    vd.clo |= mine ? (1u << ((k - 1) & 31)) : 0u;
-                else
-                    vd.chi |= mine ? (1u << ((k - 33) & 31)) : 0u;
+        if (a <= b) {
+            int2 th_next = thr_row[a - 1];
+            for (int k = a; k <= b; k++) {
+                const int2 th = th_next;
+                th_next = thr_row[k];  // entry 64 exists (padding)
+                const u64 pm = filter_k_uni<NW, WS, NWW>(P1, P2, P3, L, k, th, vd.hasm);
+                vd.hasm |= pm;
+                if (SLOW) {
+                    if (k >= kmin && k <= kmax) vd.flagm |= pm;
+                    if (dbg) {  // wave-uniform
+                        const bool mine = (pm >> lane_id()) & 1ull;
+                        if (k <= 32)
+                            vd.clo |= mine ? (1u << ((k - 1) & 31)) : 0u;
+                        else
+                            vd.chi |= mine ? (1u << ((k - 33) & 31)) : 0u;
+                    }
+                }
             }
         }
-        FilterRangeUni<NW, WS, NWW - 1>::run(P1, P2, P3, klo, khi, L, kmin, kmax, thr_row, dbg, vd);
+        FilterRangeUni<NW, WS, NWW - 1, SLOW>::run(P1, P2, P3, klo, khi, L, kmin, kmax, thr_row, dbg, vd);
     }
 };
-template <int NW, int WS>
-struct FilterRangeUni<NW, WS, 0> {
+template <int NW, int WS, bool SLOW>
+struct FilterRangeUni<NW, WS, 0, SLOW> {
     static __device__ __forceinline__ void run(const u32 (&)[NW], const u32 (&)[NW], const u32 (&)[NW], int, int, int, int, int, const int2 *,
                                                bool, UniVerdict &) {}
 };
@@ -396,9 +431,16 @@ __device__ __forceinline__ void filter_segment_uni(const u32 (&lo)[NW], const u3
     vd.hasm = vd.flagm = 0;
     vd.clo = vd.chi = 0;
     const int g31 = gmax < 31 ? gmax : 31;
-    FilterRangeUni<NW, 0, NW>::run(P1, P2, P3, gmin, g31, L, kmin, kmax, thr_row, dbg, vd);
-    FilterRangeUni<NW, 1, NW>::run(P1, P2, P3, gmin > 32 ? gmin : 32, gmax < 63 ? gmax : 63, L, kmin, kmax, thr_row, dbg, vd);
-    FilterRangeUni<NW, 2, NW>::run(P1, P2, P3, gmin > 64 ? gmin : 64, gmax, L, kmin, kmax, thr_row, dbg, vd);
+    if (dbg || kmin > gmin || kmax < gmax) {  // wave-uniform
+        FilterRangeUni<NW, 0, NW, true>::run(P1, P2, P3, gmin, g31, L, kmin, kmax, thr_row, dbg, vd);
+        FilterRangeUni<NW, 1, NW, true>::run(P1, P2, P3, gmin > 32 ? gmin : 32, gmax < 63 ? gmax : 63, L, kmin, kmax, thr_row, dbg, vd);
+        FilterRangeUni<NW, 2, NW, true>::run(P1, P2, P3, gmin > 64 ? gmin : 64, gmax, L, kmin, kmax, thr_row, dbg, vd);
+    } else {
+        FilterRangeUni<NW, 0, NW, false>::run(P1, P2, P3, gmin, g31, L, kmin, kmax, thr_row, false, vd);
+        FilterRangeUni<NW, 1, NW, false>::run(P1, P2, P3, gmin > 32 ? gmin : 32, gmax < 63 ? gmax : 63, L, kmin, kmax, thr_row, false, vd);
+        FilterRangeUni<NW, 2, NW, false>::run(P1, P2, P3, gmin > 64 ? gmin : 64, gmax, L, kmin, kmax, thr_row, false, vd);
+        vd.flagm = vd.hasm;
+    }
 }
 
 constexpr u32 kStage = 1024;  // unit indices a block stages in LDS before one global append
@@ -500,12 +542,12 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
     // 256 units are waiting (or the input is exhausted) the general path drains them.
     __shared__ u32 defer[kDefer];
     __shared__ u32 defer_n;
-    __shared__ int2 thr_tab[kMaxSlots][64];
+    __shared__ int2 thr_tab[kMaxSlots][65];  // [k-1]; one entry of padding for the read-ahead
     const u32 UL = B.uniform_length;
     const bool uni = NW <= 5 && UL != 0 && P.mode != TREW_MODE_LONG && !(P.flags & TREW_FLAG_NO_FILTER);
     if (uni) {
-        for (u32 i = threadIdx.x; i < (u32) kMaxSlots * 64u; i += blockDim.x) {
-            const int slot = (int) (i >> 6), k = (int) (i & 63u) + 1;
+        for (u32 i = threadIdx.x; i < (u32) kMaxSlots * 65u; i += blockDim.x) {
+            const int slot = (int) (i / 65u), k = (int) (i % 65u) + 1;
             const Segment sg = get_segment(P.mode, slot, UL, UL, P.min_mer, P.max_mer, P.slice_len);
             const int W = (int) sg.len - k + 1;
             int2 th;
@@ -781,6 +823,20 @@ __device__ __forceinline__ u32 *sm_ccnt(ExactSmem sm) { return sm_cpart(sm) + kC
 template <typename WT>
 __device__ __forceinline__ WT *sm_canon(ExactSmem sm) { return (WT *) (lds0() + exact_lds_fixed(sm.cap, sm.rawwords)); }
 
+__device__ __forceinline__ ExactSmem uni(ExactSmem sm) {
+    sm.cap = rfl(sm.cap);
+    sm.rawwords = rfl(sm.rawwords);
+    return sm;
+}
+__device__ __forceinline__ DevTable uni(DevTable T) {
+    T.keys = rfl_ptr(T.keys);
+    T.counts = rfl_ptr(T.counts);
+    T.log2_part_slots = rfl(T.log2_part_slots);
+    T.overflow = rfl_ptr(T.overflow);
+    T.wide = rfl_ptr(T.wide);
+    return T;
+}
+
 __device__ __forceinline__ u64 spread32(u32 v) {
     u64 x = v;
     x = (x | (x << 16)) & 0x0000ffff0000ffffull;
@@ -803,8 +859,14 @@ __device__ ReadRef stage_read(ExactSmem sm, const ReadRef &rd, int mate) {
     return r;
 }
 
-__attribute__((noinline)) __device__ void load_segment(ExactSmem sm, const ReadRef &rd, u32 s, u32 L) {
+__attribute__((noinline)) __device__ void load_segment(ExactSmem sm, ReadRef rd, u32 s, u32 L) {
     PH_T0(t_ph);
+    sm = uni(sm);
+    rd.w = rfl_ptr(rd.w);
+    rd.len = rfl(rd.len);
+    rd.nw = rfl(rd.nw);
+    s = rfl(s);
+    L = rfl(L);
     __syncthreads();
     const u32 nwords = (L + 31u) >> 5;
     const u32 segwords = sm.cap / 32 + 2;
@@ -849,10 +911,16 @@ template <typename WT>
 __device__ __forceinline__ WT min_rotation(WT w, int k) {
     const int sh = 2 * (k - 1);
     if (k <= 16) {  // wave-uniform: the 2k-bit word fits 32 bits
-        u32 tmp = (u32) w, ans = (u32) w;
-        for (int i = 0; i < k - 1; i++) {
-            tmp = ((tmp & 3u) << sh) | (tmp >> 2);
-            ans = min(ans, tmp);
+        // rotation i (right by i bases) = bits [2i, 2i+2k) of the word written twice
+        const u32 w32 = (u32) w;
+        const u64 dup = ((u64) w32 << (2 * k)) | w32;
+        const u32 dlo = (u32) dup, dhi = (u32) (dup >> 32);
+        const u32 km = 2 * k >= 32 ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+        u32 ans = w32;
+        if (k <= 8) {  // the doubled word fits 32 bits: one bit-field extract per rotation
+            for (int i = 1; i < k; i++) ans = min(ans, __builtin_amdgcn_ubfe(dlo, 2u * (u32) i, 2u * (u32) k));
+        } else {
+            for (int i = 1; i < k; i++) ans = min(ans, alignbit(dhi, dlo, 2u * (u32) i) & km);
         }
         return ans;
     }
@@ -938,9 +1006,7 @@ __device__ __forceinline__ bool window_valid(ExactSmem sm, u32 i, int k) {  // k
 // (strict '<' at kmer.cpp:2202).  key = (class size << 16) | (0xffff - last window)
 template <typename WT>
 __device__ __forceinline__ void wave_best(u32 best, WT best_seq, KStat<WT> &st) {
-    u32 m = best;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (u32) __shfl_xor((int) m, off));
+    const u32 m = wave_max_u32(best);
     const u64 who = __ballot(best == m && m != 0);
     if (who) {
         const int src = __ffsll((long long) who) - 1;
@@ -956,6 +1022,10 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k_windows(ExactSmem sm, int 
     KStat<WT> st;  // returned by value: a reference parameter of a noinline function lives in scratch memory
     PH_T0(t_ph);
     PH_CNT(PH_N_WINDOWS_CALLS, 1);
+    sm = uni(sm);
+    W = rfl_i(W);
+    k = rfl_i(k);
+    count = rfl(count);
     st.count = count;
     st.maxc = 0;
     st.maxseq = 0;
@@ -1030,6 +1100,10 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k
     st.maxseq = 0;
     st.n_items = 0;
     st.pruned = false;
+    sm = uni(sm);
+    L = rfl_i(L);
+    k = rfl_i(k);
+    need = rfl_f64(need);
     const int W = L - k + 1;
     if (W <= 0) return st;
     PH_T0(t_ph);
@@ -1100,6 +1174,9 @@ __attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, in
     st.maxseq = 0;
     st.n_items = 0;
     st.pruned = false;
+    sm = uni(sm);
+    W = rfl_i(W);
+    k = rfl_i(k);
     const u32 lane = lane_id();
     const int rounds = (W + 63) >> 6;
     PH_T0(t_ph);
@@ -1230,6 +1307,12 @@ __device__ void cache_flush(ExactSmem sm, DevTable T) {
 // rotation-canonical word itself (k_mer_check, kmer.cpp:2264-2313).
 template <typename WT>
 __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n_items, int k, u32 table_mask, bool strand_canon) {
+    sm = uni(sm);
+    T = uni(T);
+    n_items = rfl(n_items);
+    k = rfl_i(k);
+    table_mask = rfl(table_mask);
+    strand_canon = rfl((u32) strand_canon) != 0;
     const u32 lane = lane_id();
     PH_T0(t_ph);
     for (u32 i = lane; i < n_items; i += 64) {
