@@ -1728,8 +1728,11 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     // pass 1: forward chain (kmer.cpp:797-817)
     int si[2] = {1, 1}, kmer[2] = {0, 0}, last_rec[2] = {0, 0};
     bool rend[2] = {false, false};
+    // decisions of the first 64 slices, one per lane (kh | kl << 8), so that pass 2 does not decide them again
+    u32 dcache = 0;
     for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {
         const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+        if ((int) lane_id() == ti - 1) dcache = (u32) d.kh | ((u32) d.kl << 8);
         const int tk[2] = {d.kh, d.kl};
 #pragma unroll
         for (int b = 0; b < 2; b++) {
@@ -1750,7 +1753,20 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const u32 th = canon_h ? TREW_TABLE_BOTH_HIGH : TREW_TABLE_FORWARD_HIGH;
         const u32 tl = canon_l ? TREW_TABLE_BOTH_LOW : TREW_TABLE_FORWARD_LOW;
         for (int ti = 1; ti <= upto; ti++) {
-            const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+            Decision<WT> d;
+            if (ti <= 64) {
+                const u32 c = (u32) __builtin_amdgcn_readlane((int) dcache, ti - 1);
+                d.kh = (int) (c & 255u);
+                d.kl = (int) (c >> 8);
+                d.sh = d.sl = 0;
+                if ((ti <= last_rec[0] && d.kh > 0) || (ti <= last_rec[1] && d.kl > 0)) {  // record() wants the slice staged
+                    u32 st, sl;
+                    long_slice(ti, mid, bonus, SL, st, sl);
+                    load_segment(sm, rd, st, sl);
+                }
+            } else {
+                d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+            }
             const bool rh = ti <= last_rec[0] && d.kh > 0, rl = ti <= last_rec[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl && canon_h == canon_l) {
                 record<WT>(sm, T, slice_len(ti), d.kh, (1u << th) | (1u << tl), canon_h);
