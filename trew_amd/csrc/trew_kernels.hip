@@ -1720,6 +1720,12 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         u32 st, sl;
         long_slice(t, mid, bonus, SL, st, sl);
         load_segment(sm, rd, st, sl);
+        if (NW > 5 && sl <= 159u) {  // every slice but the middle one is SLICE_LENGTH long: half the mask words
+            constexpr int NS = NW > 5 ? 5 : NWB;
+            LaneMasks<NS> m5;
+            lane_bounds<NS>(rd, st, (int) sl, P.min_mer, P.max_mer, m5);
+            return decide<(NW > 5 ? 5 : NW), WT>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m5);
+        }
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(rd, st, (int) sl, P.min_mer, P.max_mer, m);
         return decide<NW, WT>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m);
