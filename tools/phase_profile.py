@@ -11,16 +11,22 @@ from trew_amd import capi
 mode = sys.argv[1] if len(sys.argv) > 1 else "short"
 lib = capi.load()
 n, L = 10_000_000, 150
-t = T.TrewHip(mode=T.MODE_SHORT, n_slots=1, max_batch_words=16, max_batch_reads=n, table_log2_slots=20)
-d = t.malloc(n * 60 + 64)
-t.synth_short_device(20250218, 0, n, L, d)
-b = t.device_uniform_batch(d, n, L)
+if mode == "pair":
+    t = T.TrewHip(mode=T.MODE_PAIR, n_slots=1, max_batch_words=16, max_batch_reads=2 * n, table_log2_slots=20)
+    d = t.malloc(2 * n * 60 + 64)
+    t.synth_pair_device(20250218, 0, n, L, d)
+    b = t.device_uniform_batch(d, 2 * n, L)
+else:
+    t = T.TrewHip(mode=T.MODE_SHORT, n_slots=1, max_batch_words=16, max_batch_reads=n, table_log2_slots=20)
+    d = t.malloc(n * 60 + 64)
+    t.synth_short_device(20250218, 0, n, L, d)
+    b = t.device_uniform_batch(d, n, L)
 out = (C.c_ulonglong * 32)()
 for rnd in range(3):
     t.submit(b, 0)
     t.wait(0)
     lib.trew_debug_phases(out, 1)
-names = ["total", "stage", "loadseg", "bounds", "decide", "runs", "windows", "record_eval", "emit", "flush", "evalk_A"]
+names = ["total", "stage", "loadseg", "bounds", "decide", "runs", "windows", "record_eval", "emit", "flush", "evalk_A", "pair_stage", "pair_flush", "pair_fwd", "pair_bwd", "pair_whole"]
 tot = out[0]
 a, e, fl = t.last_timing(0)
 print("filter %.4f ms exact %.4f ms flagged %d" % (a, e, fl))

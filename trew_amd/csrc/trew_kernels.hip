@@ -79,6 +79,13 @@ struct ReadRef {
     u32 len;       // bases
     u32 nw;        // triples
 };
+// one wave works on one read: its descriptor is wave-uniform
+__device__ __forceinline__ ReadRef uni(ReadRef r) {
+    r.w = rfl_ptr(r.w);
+    r.len = rfl(r.len);
+    r.nw = rfl(r.nw);
+    return r;
+}
 
 __device__ __forceinline__ ReadRef get_read(const DevBatch &b, u64 r) {
     ReadRef x;
@@ -806,7 +813,7 @@ __device__ __forceinline__ unsigned long long *ph_lds() {
 #define PH_ADD(i, v)
 #define PH_CNT(i, c)
 #endif
-enum { PH_TOTAL = 0, PH_STAGE, PH_LOADSEG, PH_BOUNDS, PH_DECIDE, PH_RUNS, PH_WINDOWS, PH_RECORD_EVAL, PH_EMIT, PH_FLUSH, PH_EVALK_A,
+enum { PH_TOTAL = 0, PH_STAGE, PH_LOADSEG, PH_BOUNDS, PH_DECIDE, PH_RUNS, PH_WINDOWS, PH_RECORD_EVAL, PH_EMIT, PH_FLUSH, PH_EVALK_A, PH_PAIR_STAGE, PH_PAIR_FLUSH, PH_PAIR_FWD, PH_PAIR_BWD, PH_PAIR_WHOLE,
        PH_N_READS = 16, PH_N_RUNS_CALLS, PH_N_WINDOWS_CALLS, PH_N_RECORD, PH_N_RUNS_TOTAL, PH_N_K5 };
 
 __device__ __forceinline__ u64 *sm_seq(ExactSmem sm) { return (u64 *) lds0(); }
@@ -971,6 +978,20 @@ struct KStat {
     u32 n_items; // entries of canon[]/cnt[] left in LDS for emit_k
     bool pruned; // the bucket bound proved MAX/COUNT < need: maxc/maxseq were not computed
 };
+
+__device__ __forceinline__ u64 rfl_word(u64 v) { return rfl64(v); }
+__device__ __forceinline__ u128 rfl_word(u128 v) { return ((u128) rfl64((u64) (v >> 64)) << 64) | rfl64((u64) v); }
+// A KStat / Decision returned by a noinline function arrives in VGPRs; every field is wave-uniform.
+// Saying so keeps the drivers' control state (chain counters, thresholds, intent lists) in SGPRs.
+template <typename WT>
+__device__ __forceinline__ KStat<WT> uni(KStat<WT> st) {
+    st.count = rfl(st.count);
+    st.maxc = rfl(st.maxc);
+    st.maxseq = rfl_word(st.maxseq);
+    st.n_items = rfl(st.n_items);
+    st.pruned = rfl((u32) st.pruned) != 0;
+    return st;
+}
 
 __device__ __forceinline__ u32 base_at(ExactSmem sm, u32 p) {
     return (u32) (sm_seq(sm)[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
@@ -1536,10 +1557,10 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
                     em[nq] = 0;
                 }
                 __syncthreads();
-                st = eval_runs<WT>(sm, W, k);
+                st = uni(eval_runs<WT>(sm, W, k));
             }
         } else {
-            st = eval_k<WT>(sm, L, k, need);
+            st = uni(eval_k<WT>(sm, L, k, need));
         }
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
@@ -1567,7 +1588,7 @@ __device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_
     if (k <= 0 || table_mask == 0) return;
     PH_T0(t_ph);
     PH_CNT(PH_N_RECORD, 1);
-    const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
+    const KStat<WT> st = uni(eval_k<WT>(sm, L, k, 0.0));
     PH_ADD(PH_RECORD_EVAL, t_ph);
     emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
 }
@@ -1577,7 +1598,7 @@ template <typename WT>
 __device__ void target(ExactSmem sm, const DevParams &P, const DevTable &T, int L, int k, bool want_high, bool want_low) {
     PH_T0(t_ph);
     PH_CNT(PH_N_RECORD, 1);
-    const KStat<WT> st = eval_k<WT>(sm, L, k, 0.0);
+    const KStat<WT> st = uni(eval_k<WT>(sm, L, k, 0.0));
     PH_ADD(PH_RECORD_EVAL, t_ph);
     if (st.count == 0) return;
     const double f = is_homopolymer<WT>(st.maxseq, k) ? 0.0 : (double) st.maxc / (double) st.count;
@@ -1709,7 +1730,7 @@ template <int NW, typename WT>
 __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const ReadRef rd = get_read(B, unit);
+    const ReadRef rd = uni(get_read(B, rfl(unit)));
     const int SL = P.slice_len;
     const int len = (int) rd.len;
     const int snum = len / SL;
@@ -1833,27 +1854,52 @@ template <int NW, typename WT>
 __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, const DevTable &T, u32 unit_in) {
     constexpr bool UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
-    const u64 unit = unit_in;
-    const ReadRef r0 = stage_read(sm, get_read(B, 2ull * unit), 0);
-    const ReadRef r1 = stage_read(sm, get_read(B, 2ull * unit + 1), 1);
+    const u64 unit = rfl(unit_in);
+    PH_T0(t_st);
+    const ReadRef r0 = uni(stage_read(sm, uni(get_read(B, 2ull * unit)), 0));
+    const ReadRef r1 = uni(stage_read(sm, uni(get_read(B, 2ull * unit + 1)), 1));
+    PH_ADD(PH_PAIR_STAGE, t_st);
+    PH_CNT(PH_N_READS, 1);
     const int n1 = (int) r0.len, n2 = (int) r1.len;
     const int n = n1 < n2 ? n1 : n2;
     if (2 * P.min_mer > n) return;
-    u32 *intent = sm_intent(sm);
+    // the intent list lives in a register, entry i in lane i: reading it back is a readlane, not an
+    // LDS round trip (the list is scanned quadratically by flush(); in LDS that was 20 % of the kernel)
+    u32 my_intent = 0;
     u32 n_int = 0;
     const u32 lane = lane_id();
     auto seg_of = [&](int slot) { return get_segment(TREW_MODE_PAIR, slot, (u32) n1, (u32) n2, P.min_mer, P.max_mer, P.slice_len); };
+    // k_mer_check is a pure function of the segment: the backward chain reuses what the forward
+    // chain decided (slot s cached in lane s)
+    u32 dc_k = 0, dc_have = 0;
+    WT dc_sh = 0, dc_sl = 0;
     auto seg_decide = [&](int slot) {
+        if ((dc_have >> slot) & 1u) {
+            Decision<WT> d;
+            const u32 c = (u32) __builtin_amdgcn_readlane((int) dc_k, slot);
+            d.kh = (int) (c & 255u);
+            d.kl = (int) (c >> 8);
+            d.sh = readlane_word(dc_sh, slot);
+            d.sl = readlane_word(dc_sl, slot);
+            return d;
+        }
         const Segment sg = seg_of(slot);
         const ReadRef &r = sg.mate ? r1 : r0;
         load_segment(sm, r, sg.start, sg.len);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
-        return decide<NW, WT>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        const Decision<WT> d = decide<NW, WT>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        if ((int) lane == slot) {
+            dc_k = (u32) d.kh | ((u32) d.kl << 8);
+            dc_sh = d.sh;
+            dc_sl = d.sl;
+        }
+        dc_have |= 1u << slot;
+        return d;
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
         if (k > 0 && n_int < 32) {
-            if (lane == 0) intent[n_int] = pack_intent(slot, k, b, temp);
+            if (lane == n_int) my_intent = pack_intent(slot, k, b, temp);
             n_int++;
         }
     };
@@ -1862,33 +1908,35 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     // intents with equal (slot, k) share one evaluation.
     // plain/canon: byte (2*temp + baseline) = table mask (packed so nothing is indexed in scratch)
     auto flush = [&](u32 plain, u32 canon, u32 bmask, bool clear) {
-        __syncthreads();
+        PH_T0(t_fl);
         for (u32 i = 0; i < n_int; i++) {
-            const u32 e = rfl(intent[i]);
+            const u32 e = (u32) __builtin_amdgcn_readlane((int) my_intent, (int) i);
             if (!(e >> 12) || !((bmask >> ((e >> 10) & 1u)) & 1u)) continue;  // consumed earlier / other baseline
             const int slot = (int) (e & 7u), k = (int) ((e >> 3) & 127u);
             u32 mp = 0, mc = 0;
             for (u32 j = i; j < n_int; j++) {
-                const u32 f = rfl(intent[j]);
+                const u32 f = (u32) __builtin_amdgcn_readlane((int) my_intent, (int) j);
                 const u32 fb = (f >> 10) & 1u;
                 if ((f >> 12) && ((bmask >> fb) & 1u) && (int) (f & 7u) == slot && (int) ((f >> 3) & 127u) == k) {
                     const u32 temp = (f >> 11) & 1u;
                     mp |= (plain >> (8u * (2u * temp + fb))) & 0xffu;
                     mc |= (canon >> (8u * (2u * temp + fb))) & 0xffu;
-                    if (lane == 0) intent[j] = 0;
+                    if (lane == j) my_intent = 0;
                 }
             }
-            __syncthreads();
             if (mp | mc) {
                 const Segment sg = seg_of(slot);
                 load_segment(sm, sg.mate ? r1 : r0, sg.start, sg.len);
-                const KStat<WT> st = eval_k<WT>(sm, (int) sg.len, k, 0.0);
+                const KStat<WT> st = uni(eval_k<WT>(sm, (int) sg.len, k, 0.0));
                 if (mp) emit_k<WT>(sm, T, st.n_items, k, mp, false);
                 if (mc) emit_k<WT>(sm, T, st.n_items, k, mc, true);
             }
         }
-        if (clear) n_int = 0;
-        __syncthreads();
+        if (clear) {
+            n_int = 0;
+            my_intent = 0;
+        }
+        PH_ADD(PH_PAIR_FLUSH, t_fl);
     };
     int lef_k[2] = {0, 0}, kmer[2] = {0, 0};
     WT kseq[2] = {0, 0};
@@ -1897,6 +1945,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const int snum = 4;
         int si[2] = {1, 1};
         bool rend[2] = {false, false};
+        PH_T0(t_fw);
         for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {  // kmer.cpp:347-374
             const Decision<WT> d = seg_decide(ti - 1);
             const int tk[2] = {d.kh, d.kl};
@@ -1913,6 +1962,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                 }
             }
         }
+        PH_ADD(PH_PAIR_FWD, t_fw);
         lef_k[0] = kmer[0];
         lef_k[1] = kmer[1];
         // all four segments chained: both temps -> both, strand-canonical (kmer.cpp:378-399).
@@ -1934,7 +1984,9 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             int sj[2] = {snum, snum};
             kmer[0] = kmer[1] = 0;
             rend[0] = rend[1] = false;
+            PH_T0(t_bw);
             for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
+                PH_CNT(PH_N_RECORD, 1);
                 const Decision<WT> d = seg_decide(tj - 1);
                 const int tk[2] = {d.kh, d.kl};
                 const WT ts[2] = {d.sh, d.sl};
@@ -1951,6 +2003,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                     }
                 }
             }
+            PH_ADD(PH_PAIR_BWD, t_bw);
         }
         {  // kmer.cpp:438-455: temp_left -> forward, temp_right -> backward for a baseline that did not complete
             u32 plain = 0;
@@ -1960,6 +2013,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
     }
     if (4 * P.max_mer > n) {  // whole-read block, kmer.cpp:467-505
+        PH_T0(t_wh);
         Decision<WT> lt = {0, 0, 0, 0}, rt = {0, 0, 0, 0};
         if (lef_k[0] == 0 || lef_k[1] == 0) {
             lt = seg_decide(4);
@@ -1978,6 +2032,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         if (lef_k[1] == 0 && kmer[1] == 0 && lt.kl == rt.kl && lt.kl > 0 && lt.sl == min_rotation<WT>(revcomp(rt.sl, rt.kl), rt.kl))
             canon |= dest(0, 1, TREW_TABLE_BOTH_LOW);
         flush(plain, canon, 3u, true);
+        PH_ADD(PH_PAIR_WHOLE, t_wh);
     }
 }
 
