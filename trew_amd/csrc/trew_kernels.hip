@@ -2040,7 +2040,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
 // NW > 0: every staged segment fits 32*NW-1 bases and decide() prunes with lane_bounds<NW>;
 // NW == 0: long segments, pruning happens inside eval_k instead.
 template <int NW, int MODE, typename WT>
-__global__ __launch_bounds__(64, ((MODE == TREW_MODE_PAIR || NW >= 10) ? 4 : 6)) void exact_kernel(DevParams P, DevBatch B, DevTable T, const u32 *wl,
+__global__ __launch_bounds__(64, (NW >= 10 ? 4 : 6)) void exact_kernel(DevParams P, DevBatch B, DevTable T, const u32 *wl,
                                                    u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
     ExactSmem sm;
     sm.cap = cap;
