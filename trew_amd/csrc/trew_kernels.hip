@@ -168,9 +168,9 @@ __device__ __forceinline__ u32 shr_word(const u32 (&x)[NW], int j, u32 bs) {
 // bound.  Lanes that already own a candidate keep the looser -- still sound -- verdict:
 // the exact kernel prunes their extra candidates itself (lane_bounds).  The result of
 // a lane never depends on its neighbours: 8-bucket max <= 4-bucket max.
-// Measured on MI355X (tools/valu_rate.hip): v_alignbit / v_bcnt / v_bitop3 issue at ~4.3
-// cycles per wave-instruction, VOP2 logic at ~1.5; the slow ones are what is minimised here
-// (e.g. bucket 00 is COUNT minus the other three instead of a fourth popcount).
+// Measured on MI355X (tools/valu_rate.hip): v_alignbit / v_bcnt occupy a SIMD for ~4.2 cycles
+// per wave-instruction, simple logic / add / v_bitop3 for ~2.3-2.7; the slow ones are what is
+// minimised here (e.g. bucket 00 is COUNT minus the other three instead of a fourth popcount).
 template <int NW, int WS, int NWW>
 __device__ __forceinline__ void filter_k(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW],
                                          const u32 (&v1)[NW], u32 (&V)[NW], int k, float lowf, u32 &cand_lo, u32 &cand_hi) {
