@@ -30,8 +30,8 @@ EVALS_PER_150BP_READ = 3220  # (window,k) evaluations per 150-bp read at 5 32 (S
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (config 2: 10M x 150 bp)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-mer", type=int, default=5)
@@ -49,7 +49,7 @@ def main():
 
     import trew_amd as T
     from trew_amd import capi
-    from trew_amd.dist import allreduce_rows
+    from trew_amd.dist import allreduce_rows_into_table
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -121,7 +121,7 @@ def main():
     filt_ms.append(a)
     exact_ms.append(b)
     rows = t.collect_rows()
-    merged = allreduce_rows(rows, device=comm_dev)
+    merged = allreduce_rows_into_table(t, rows, device=comm_dev)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -7,7 +7,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from trew_amd import capi
-from trew_amd.dist import allreduce_rows, allreduce_tables, shard_range
+from trew_amd.dist import allreduce_rows, allreduce_rows_into_table, allreduce_tables, shard_range
 
 
 def _make(rank):
@@ -22,6 +22,22 @@ def _make(rank):
     return t
 
 
+class _HostTable:
+    """Stands in for the device count table of trew_amd.capi.TrewHip on a box without a GPU:
+    add_rows() sums into a dict, collect_rows() returns the rows (what the HIP table does with atomics)."""
+
+    def __init__(self, tables):
+        self.t = {name: dict(d) for name, d in tables.items()}
+
+    def add_rows(self, rows):
+        for name, d in capi.rows_to_tables(rows).items():
+            for key, c in d.items():
+                self.t[name][key] = self.t[name].get(key, 0) + c
+
+    def collect_rows(self):
+        return capi.tables_to_rows(self.t)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,7 +45,8 @@ def _worker(rank, world, port, q):
     mine = _make(rank)
     merged = allreduce_tables(mine)
     rows = allreduce_rows(capi.tables_to_rows(mine))
-    q.put((rank, merged, capi.rows_to_tables(rows)))
+    via_table = allreduce_rows_into_table(_HostTable(mine), capi.tables_to_rows(mine))
+    q.put((rank, merged, capi.rows_to_tables(rows), capi.rows_to_tables(via_table)))
     dist.destroy_process_group()
 
 
@@ -50,9 +67,10 @@ def test_allreduce_tables_gloo_world2():
         for name, d in _make(r).items():
             for key, c in d.items():
                 want[name][key] = want[name].get(key, 0) + c
-    for rank, merged, merged_rows in res:
+    for rank, merged, merged_rows, merged_via_table in res:
         assert merged == want
         assert merged_rows == want
+        assert merged_via_table == want
 
 
 def test_single_process_passthrough_and_shards():
@@ -60,6 +78,7 @@ def test_single_process_passthrough_and_shards():
     assert allreduce_tables(t) == t
     rows = capi.tables_to_rows(t)
     assert capi.rows_to_tables(allreduce_rows(rows)) == t
+    assert capi.rows_to_tables(allreduce_rows_into_table(_HostTable(t), rows)) == t
     n, w = 1_000_000_007, 8
     cover = [shard_range(n, r, w) for r in range(w)]
     assert cover[0][0] == 0 and cover[-1][1] == n
