@@ -74,6 +74,18 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {
     return (u32) __builtin_amdgcn_readlane((int) v, 63);
 }
 
+// wave sum of a u32, every lane gets the result: Hillis-Steele inside each row of 16 lanes (row_shr
+// 1, 2, 4, 8), then the row totals are passed on with the two row broadcasts; lane 63 holds the sum
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, true);
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, true);
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, true);
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, true);
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (u32) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 struct ReadRef {
     const u32 *w;  // first triple
     u32 len;       // bases
@@ -1246,15 +1258,25 @@ __attribute__((noinline)) __device__ KStat<WT> eval_runs(ExactSmem sm, int W, in
     }
     const u32 end = s + len - 1;
     u32 tot = 0, last = 0;
-    bool first = true;
-    for (u32 rp = 0; rp < R; rp++) {  // wave-uniform: broadcast run rp to every lane, no LDS round trip
-        const WT other = readlane_word(canon, (int) rp);
-        const u32 olen = (u32) __builtin_amdgcn_readlane((int) len, (int) rp);
-        const u32 oend = (u32) __builtin_amdgcn_readlane((int) end, (int) rp);
-        const bool eq = other == canon;
-        tot += eq ? olen : 0u;
-        last = eq ? oend : last;
-        first = first && !(eq && rp < lane);
+    bool first = false;
+    // One iteration per CLASS, not per run: the lowest run without a class is its leader, one ballot
+    // finds every member, a DPP sum adds their lengths; runs are in position order, so the member in
+    // the highest lane ends last.  (A TTAGGG read probed at k = 5 has ~50 runs in ~8 classes.)
+    const u64 act = R >= 64u ? ~0ull : ((1ull << R) - 1ull);
+    u64 remaining = act;
+    while (remaining) {
+        const int rp = __ffsll((long long) remaining) - 1;
+        const WT other = readlane_word(canon, rp);
+        const u64 eqm = __ballot(other == canon) & act;
+        remaining &= ~eqm;
+        const bool eq = (eqm >> lane) & 1ull;
+        const u32 total = wave_sum_u32(eq ? len : 0u);
+        const u32 oend = (u32) __builtin_amdgcn_readlane((int) end, 63 - __clzll((long long) eqm));
+        if (eq) {
+            tot = total;
+            last = oend;
+            first = (int) lane == rp;
+        }
     }
     u32 key = 0;
     if (lane < R) {
