@@ -773,10 +773,14 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 // 8 waves per SIMD stay resident and hide the global/LDS latency chains.
 // The struct only carries the two sizes (it travels in SGPRs); every array is an
 // offset from the dynamic-LDS base so that accesses compile to ds_* instructions.
-//   seq   [cap/32+2] u64  2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
+//   seq   [2][cap/32+2] u64  2-bit bases, first base most significant (KmerSeq orientation, kmer.h:77)
 //   vmask [cap/64+2] u64  bit i: window i has no N
 //   emask [cap/64+2] u64  bit i: base i == base i+k (Lemma A: windows i, i+1 share a class)
-//   nmask [cap/32+2] u32  bit i = base i is not A/C/G/T or lies past the segment end
+//   nmask [2][cap/32+2] u32  bit i = base i is not A/C/G/T or lies past the end of the staged range
+// seq/nmask hold a whole read (two of them: both mates of a pair), staged ONCE per read; a segment
+// is a view: s0 = its first base inside the staged bases.  Windows never reach past the segment
+// (i < L-k+1), so the view needs no end mask of its own.  Long reads do not fit: the long driver
+// stages one slice at a time at base 0.
 //   raw   [4][rawwords] u32  packed triples of the chunk's reads (or of the two mates), staged once
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
@@ -785,11 +789,13 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 //   canon [cap]  WT   per run (fast path) or per window (fallback); WT = u64 (k <= 32) or u128
 struct ExactSmem {
     u32 cap, rawwords;
+    u32 s0;  // first base of the current segment within the staged bases
 };
+__host__ __device__ inline u32 exact_rangewords(u32 cap) { return cap / 32 + 2; }  // words of one staged range (+ read-ahead)
 
 constexpr u32 kCacheSlots = 128;
 __host__ __device__ inline u32 exact_lds_precache(u32 cap, u32 rawwords) {  // everything before the count cache, 16-byte aligned
-    const u32 b = (cap / 32 + 2) * 8 + 2 * (cap / 64 + 2) * 8 + (cap / 32 + 2) * 4 + 4 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
+    const u32 b = 2 * exact_rangewords(cap) * 8 + 2 * (cap / 64 + 2) * 8 + 2 * exact_rangewords(cap) * 4 + 4 * rawwords * 4 + 2 * cap * 2 + 32 * 4;
     return (b + 15u) & ~15u;
 }
 __host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
@@ -829,10 +835,10 @@ enum { PH_TOTAL = 0, PH_STAGE, PH_LOADSEG, PH_BOUNDS, PH_DECIDE, PH_RUNS, PH_WIN
        PH_N_READS = 16, PH_N_RUNS_CALLS, PH_N_WINDOWS_CALLS, PH_N_RECORD, PH_N_RUNS_TOTAL, PH_N_K5 };
 
 __device__ __forceinline__ u64 *sm_seq(ExactSmem sm) { return (u64 *) lds0(); }
-__device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_seq(sm) + (sm.cap / 32 + 2); }
+__device__ __forceinline__ u64 *sm_vmask(ExactSmem sm) { return sm_seq(sm) + 2 * exact_rangewords(sm.cap); }
 __device__ __forceinline__ u64 *sm_emask(ExactSmem sm) { return sm_vmask(sm) + (sm.cap / 64 + 2); }
 __device__ __forceinline__ u32 *sm_nmask(ExactSmem sm) { return (u32 *) (sm_emask(sm) + (sm.cap / 64 + 2)); }
-__device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + (sm.cap / 32 + 2); }
+__device__ __forceinline__ u32 *sm_raw(ExactSmem sm) { return sm_nmask(sm) + 2 * exact_rangewords(sm.cap); }
 __device__ __forceinline__ unsigned short *sm_cnt(ExactSmem sm) { return (unsigned short *) (sm_raw(sm) + 4 * sm.rawwords); }
 __device__ __forceinline__ unsigned short *sm_start(ExactSmem sm) { return sm_cnt(sm) + sm.cap; }
 __device__ __forceinline__ u32 *sm_intent(ExactSmem sm) { return (u32 *) (sm_start(sm) + sm.cap); }
@@ -845,6 +851,7 @@ __device__ __forceinline__ WT *sm_canon(ExactSmem sm) { return (WT *) (lds0() + 
 __device__ __forceinline__ ExactSmem uni(ExactSmem sm) {
     sm.cap = rfl(sm.cap);
     sm.rawwords = rfl(sm.rawwords);
+    sm.s0 = rfl(sm.s0);
     return sm;
 }
 __device__ __forceinline__ DevTable uni(DevTable T) {
@@ -878,7 +885,8 @@ __device__ ReadRef stage_read(ExactSmem sm, const ReadRef &rd, int mate) {
     return r;
 }
 
-__attribute__((noinline)) __device__ void load_segment(ExactSmem sm, ReadRef rd, u32 s, u32 L) {
+// stage bases [s, s+L) of a read as range `range` (0 or 1) of seq[] / nmask[] (one wave)
+__attribute__((noinline)) __device__ void stage_bases(ExactSmem sm, ReadRef rd, u32 s, u32 L, u32 range) {
     PH_T0(t_ph);
     sm = uni(sm);
     rd.w = rfl_ptr(rd.w);
@@ -886,9 +894,12 @@ __attribute__((noinline)) __device__ void load_segment(ExactSmem sm, ReadRef rd,
     rd.nw = rfl(rd.nw);
     s = rfl(s);
     L = rfl(L);
+    range = rfl(range);
     __syncthreads();
     const u32 nwords = (L + 31u) >> 5;
-    const u32 segwords = sm.cap / 32 + 2;
+    const u32 segwords = exact_rangewords(sm.cap);
+    u64 *seq = sm_seq(sm) + range * segwords;
+    u32 *nmk = sm_nmask(sm) + range * segwords;
     for (u32 lane = lane_id(); lane < segwords; lane += 64) {
         u64 sq = 0;
         u32 nmv = 0xffffffffu;
@@ -901,11 +912,24 @@ __attribute__((noinline)) __device__ void load_segment(ExactSmem sm, ReadRef rd,
             const u32 l = lo[0] & ~nmv, h = hi[0] & ~nmv;
             sq = spread32(__brev(l)) | (spread32(__brev(h)) << 1);
         }
-        sm_seq(sm)[lane] = sq;
-        sm_nmask(sm)[lane] = nmv;
+        seq[lane] = sq;
+        nmk[lane] = nmv;
     }
     __syncthreads();
     PH_ADD(PH_LOADSEG, t_ph);
+}
+// first base of staged range r
+__device__ __forceinline__ u32 range_base(ExactSmem sm, u32 r) { return r * 32u * exact_rangewords(sm.cap); }
+// the segment [s, s+L) of a read whose bases are staged as range r: a view, nothing moves
+__device__ __forceinline__ ExactSmem view_segment(ExactSmem sm, u32 r, u32 s) {
+    sm.s0 = range_base(sm, r) + s;
+    return sm;
+}
+// long mode: stage one slice at base 0 and look at it
+__device__ __forceinline__ ExactSmem load_segment(ExactSmem sm, ReadRef rd, u32 s, u32 L) {
+    stage_bases(sm, rd, s, L, 0);
+    sm.s0 = 0;
+    return sm;
 }
 
 
@@ -1006,12 +1030,14 @@ __device__ __forceinline__ KStat<WT> uni(KStat<WT> st) {
 }
 
 __device__ __forceinline__ u32 base_at(ExactSmem sm, u32 p) {
+    p += sm.s0;
     return (u32) (sm_seq(sm)[p >> 5] >> (62u - 2u * (p & 31u))) & 3u;
 }
 template <typename WT>
 __device__ __forceinline__ WT window_word(ExactSmem sm, u32 i, int k);
 template <>
 __device__ __forceinline__ u64 window_word<u64>(ExactSmem sm, u32 i, int k) {
+    i += sm.s0;
     const u32 wi = i >> 5, sh = 2u * (i & 31u);
     const u64 a = sm_seq(sm)[wi], b = sm_seq(sm)[wi + 1];
     const u64 x = sh ? ((a << sh) | (b >> (64u - sh))) : a;
@@ -1019,6 +1045,7 @@ __device__ __forceinline__ u64 window_word<u64>(ExactSmem sm, u32 i, int k) {
 }
 template <>
 __device__ __forceinline__ u128 window_word<u128>(ExactSmem sm, u32 i, int k) {
+    i += sm.s0;
     const u32 wi = i >> 5, sh = 2u * (i & 31u);
     const u64 a = sm_seq(sm)[wi], b = sm_seq(sm)[wi + 1], c = sm_seq(sm)[wi + 2];
     const u128 ab = ((u128) a << 64) | b;
@@ -1026,6 +1053,7 @@ __device__ __forceinline__ u128 window_word<u128>(ExactSmem sm, u32 i, int k) {
     return x >> (128 - 2 * k);
 }
 __device__ __forceinline__ bool window_valid(ExactSmem sm, u32 i, int k) {  // k <= 64
+    i += sm.s0;
     const u32 wi = i >> 5, bi = i & 31u;
     const u64 lo = ((u64) sm_nmask(sm)[wi + 1] << 32) | sm_nmask(sm)[wi];
     const u64 hi = sm_nmask(sm)[wi + 2];
@@ -1640,15 +1668,16 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sW = get_segment(TREW_MODE_SHORT, 2, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     Decision<WT> left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
+    if (sL.valid || sW.valid) stage_bases(sm, rd, 0, (u32) n, 0);  // the whole read, once; segments are views
     if (sL.valid) {
-        load_segment(sm, rd, sL.start, sL.len);
+        sm = view_segment(sm, 0, sL.start);
         LaneMasks<NWB> mL, mR;
         if (UB) {
             lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
             lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
         }
         left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL);
-        load_segment(sm, rd, sR.start, sR.len);
+        sm = view_segment(sm, 0, sR.start);
         right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
@@ -1670,7 +1699,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
             const bool rec_h = left.kh > 0 && !tgt_h;  // temp_result_left.first -> forward.first (kmer.cpp:132-134)
             const bool rec_l = left.kl > 0 && !tgt_l;
             if (rec_h || rec_l) {
-                load_segment(sm, rd, sL.start, sL.len);
+                sm = view_segment(sm, 0, sL.start);
                 if (rec_h && rec_l && left.kh == left.kl) {
                     record<WT>(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
                 } else {
@@ -1679,7 +1708,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
                 }
             }
             if (tgt_h || tgt_l) {
-                load_segment(sm, rd, 0, (u32) n);
+                sm = view_segment(sm, 0, 0);
                 if (tgt_h && tgt_l && left.kh == left.kl) {
                     target<WT>(sm, P, T, n, left.kh, true, true);
                 } else {
@@ -1692,7 +1721,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     const bool hh = left.kh == 0 && right.kh == 0;  // kmer.cpp:165-166
     const bool lh = left.kl == 0 && right.kl == 0;
     if (sW.valid && (hh || lh)) {  // kmer.cpp:168-171
-        load_segment(sm, rd, 0, (u32) n);
+        sm = view_segment(sm, 0, 0);
         LaneMasks<NWB> mW;
         if (UB) lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer, mW);
         const Decision<WT> w = decide<NW, WT>(sm, P, n, sW.kmin, sW.kmax, ~0ull, mW);
@@ -1714,7 +1743,7 @@ __device__ void run_segment(ExactSmem sm, const DevParams &P, const DevTable &T,
     constexpr int NWB = NW > 0 ? NW : 1;
     const Segment s = get_segment(TREW_MODE_SEGMENT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     if (!s.valid) return;
-    load_segment(sm, rd, 0, s.len);
+    sm = load_segment(sm, rd, 0, s.len);
     LaneMasks<NWB> m;
     if (UB) lane_bounds<NWB>(rd, 0, (int) s.len, P.min_mer, P.max_mer, m);
     const Decision<WT> d = decide<NW, WT>(sm, P, (int) s.len, s.kmin, s.kmax, ~0ull, m);
@@ -1762,7 +1791,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     auto slice_decide = [&](int t, u64 cand) {
         u32 st, sl;
         long_slice(t, mid, bonus, SL, st, sl);
-        load_segment(sm, rd, st, sl);
+        sm = load_segment(sm, rd, st, sl);
         if (NW > 5 && sl <= 159u) {  // every slice but the middle one is SLICE_LENGTH long: half the mask words
             constexpr int NS = NW > 5 ? 5 : NWB;
             LaneMasks<NS> m5;
@@ -1811,7 +1840,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                 if ((ti <= last_rec[0] && d.kh > 0) || (ti <= last_rec[1] && d.kl > 0)) {  // record() wants the slice staged
                     u32 st, sl;
                     long_slice(ti, mid, bonus, SL, st, sl);
-                    load_segment(sm, rd, st, sl);
+                    sm = load_segment(sm, rd, st, sl);
                 }
             } else {
                 d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
@@ -1885,6 +1914,8 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     const int n1 = (int) r0.len, n2 = (int) r1.len;
     const int n = n1 < n2 ? n1 : n2;
     if (2 * P.min_mer > n) return;
+    stage_bases(sm, r0, 0, (u32) n1, 0);  // both mates, once; every segment is a view
+    stage_bases(sm, r1, 0, (u32) n2, 1);
     // the intent list lives in a register, entry i in lane i: reading it back is a readlane, not an
     // LDS round trip (the list is scanned quadratically by flush(); in LDS that was 20 % of the kernel)
     u32 my_intent = 0;
@@ -1907,10 +1938,10 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
         const Segment sg = seg_of(slot);
         const ReadRef &r = sg.mate ? r1 : r0;
-        load_segment(sm, r, sg.start, sg.len);
+        const ExactSmem sv = view_segment(sm, sg.mate, sg.start);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
-        const Decision<WT> d = decide<NW, WT>(sm, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        const Decision<WT> d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
         if ((int) lane == slot) {
             dc_k = (u32) d.kh | ((u32) d.kl << 8);
             dc_sh = d.sh;
@@ -1948,10 +1979,10 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             }
             if (mp | mc) {
                 const Segment sg = seg_of(slot);
-                load_segment(sm, sg.mate ? r1 : r0, sg.start, sg.len);
-                const KStat<WT> st = uni(eval_k<WT>(sm, (int) sg.len, k, 0.0));
-                if (mp) emit_k<WT>(sm, T, st.n_items, k, mp, false);
-                if (mc) emit_k<WT>(sm, T, st.n_items, k, mc, true);
+                const ExactSmem sv = view_segment(sm, sg.mate, sg.start);
+                const KStat<WT> st = uni(eval_k<WT>(sv, (int) sg.len, k, 0.0));
+                if (mp) emit_k<WT>(sv, T, st.n_items, k, mp, false);
+                if (mc) emit_k<WT>(sv, T, st.n_items, k, mc, true);
             }
         }
         if (clear) {
@@ -2067,6 +2098,7 @@ __global__ __launch_bounds__(64, (NW >= 10 ? 4 : 6)) void exact_kernel(DevParams
     ExactSmem sm;
     sm.cap = cap;
     sm.rawwords = rawwords;
+    sm.s0 = 0;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
 #ifdef TREW_PHASE_PROFILE
