@@ -1422,10 +1422,25 @@ struct LaneMasks {
 };
 
 template <int NW>
+__device__ __forceinline__ void lane_bounds_at(const ReadRef &rd, u32 s, int L, int k, int gmax, LaneMasks<NW> &out);
+// lane l <-> k = gmin + l of the segment [s, s+L)
+template <int NW>
 __device__ __forceinline__ void lane_bounds(const ReadRef &rd, u32 s, int L, int gmin, int gmax, LaneMasks<NW> &out) {
+    lane_bounds_at<NW>(rd, s, L, gmin + (int) lane_id(), gmax, out);
+}
+// Two segments of one read in one pass when the k range fits half a wave (short reads: both
+// halves): lanes 0..31 take segment A, lanes 32..63 segment B, k = gmin + (lane & 31).
+template <int NW>
+__device__ __forceinline__ void lane_bounds_pair(const ReadRef &rd, u32 sA, int LA, u32 sB, int LB, int gmin, int gmax, LaneMasks<NW> &out) {
+    const bool hiHalf = lane_id() >= 32u;
+    lane_bounds_at<NW>(rd, hiHalf ? sB : sA, hiHalf ? LB : LA, gmin + (int) (lane_id() & 31u), gmax, out);
+}
+// s, L, k may differ per lane (they do in lane_bounds_pair); everything below is per-lane arithmetic
+template <int NW>
+__device__ __forceinline__ void lane_bounds_at(const ReadRef &rd, u32 s, int L, int k, int gmax, LaneMasks<NW> &out) {
     PH_T0(t_ph);
     u32 lo[NW], hi[NW], nm[NW];
-    load_planes<NW>(rd, s, lo, hi, nm);  // every lane reads the same (LDS-staged) words
+    load_planes<NW>(rd, s, lo, hi, nm);  // the lanes of one segment read the same (LDS-staged) words
     u32 v1[NW], P1[NW], P2[NW], P3[NW];
     {
         u32 f1[NW], f2[NW], f3[NW];
@@ -1442,7 +1457,6 @@ __device__ __forceinline__ void lane_bounds(const ReadRef &rd, u32 s, int L, int
         prefix_parity<NW>(f2, P2);
         prefix_parity<NW>(f3, P3);
     }
-    const int k = gmin + (int) lane_id();
     const u32 ku = (u32) k;
     u32 V[NW];
     u32 anyn = 0;
@@ -1538,7 +1552,8 @@ __device__ __forceinline__ u64 multiples_mask(int k) {
 // candidate k (non-candidates have frequency < LOW and can never be accepted)
 // M: per-lane knowledge of lane_bounds() (lane l <-> k = MIN_MER + l); ignored when NW == 0
 template <int NW, typename WT>
-__device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, const LaneMasks<(NW > 0 ? NW : 1)> &M) {
+__device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin, int kmax, u64 cand, const LaneMasks<(NW > 0 ? NW : 1)> &M,
+                               int lane_base = 0, int lane_span = 64) {
     constexpr bool HAVE_UB = NW > 0;
     constexpr int NWB = NW > 0 ? NW : 1;
     Decision<WT> d;
@@ -1551,8 +1566,10 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     u64 closed_low = 0, closed_high = 0;
     u64 todo = cand & all_k_mask(kmin, kmax);
     // lane l <-> k = MIN_MER + l (as in lane_bounds); only used when HAVE_UB
-    const int kl = P.min_mer + (int) lane_id();
+    // lanes [lane_base, lane_base + lane_span) hold this segment's bounds (lane_bounds_pair: half a wave)
+    const int kl = P.min_mer + (int) lane_id() - lane_base;
     const u32 klb = (u32) (kl - 1) & 63u;
+    const bool my_lane = (int) lane_id() >= lane_base && (int) lane_id() < lane_base + lane_span;
     for (;;) {
         const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
         const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
@@ -1565,7 +1582,7 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
             // eligibility is recomputed, so skipping is equivalent to the k-by-k walk.
             const bool lo_l = !((closed_low >> klb) & 1ull), hi_l = !((closed_high >> klb) & 1ull);
             const double need_l = lo_l ? (hi_l ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
-            const u64 el = __ballot(kl <= 64 && (lo_l || hi_l) && M.ub >= need_l);
+            const u64 el = __ballot(my_lane && kl <= 64 && (lo_l || hi_l) && M.ub >= need_l) >> lane_base;
             todo &= P.min_mer > 1 ? (el << (P.min_mer - 1)) : el;
         }
         if (!todo) break;
@@ -1576,7 +1593,7 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
         KStat<WT> st;
         if (HAVE_UB) {
-            const int src = k - P.min_mer;
+            const int src = k - P.min_mer + lane_base;
             // the window masks of this k were computed bit-parallel by lane `src`: fetch them
             // instead of walking the windows (phase A of eval_k)
             st.count = st.maxc = st.n_items = 0;
@@ -1672,13 +1689,20 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     if (sL.valid) {
         sm = view_segment(sm, 0, sL.start);
         LaneMasks<NWB> mL, mR;
+        const bool both = P.max_mer - P.min_mer < 32;  // the k range fits half a wave: both halves in one pass
         if (UB) {
-            lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
-            lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
+            if (both) {
+                lane_bounds_pair<NWB>(rd, sL.start, (int) sL.len, sR.start, (int) sR.len, P.min_mer, P.max_mer, mL);
+            } else {
+                lane_bounds<NWB>(rd, sL.start, (int) sL.len, P.min_mer, P.max_mer, mL);
+                lane_bounds<NWB>(rd, sR.start, (int) sR.len, P.min_mer, P.max_mer, mR);
+            }
         }
-        left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL);
+        const bool halves = UB && both;
+        if (halves) mR = mL;  // the right half's bounds sit in lanes 32..63 of the same registers
+        left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL, 0, halves ? 32 : 64);
         sm = view_segment(sm, 0, sR.start);
-        right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR);
+        right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR, halves ? 32 : 0, halves ? 32 : 64);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
