@@ -503,3 +503,131 @@ def test_tiny_table_spills_but_stays_exact():
         t.submit_reads(reads)
         t.wait()
         assert t.collect() == want
+
+
+def _tables_sum(a, b):
+    out = {n: dict(a[n]) for n in a}
+    for n in b:
+        for key, c in b[n].items():
+            out[n][key] = out[n].get(key, 0) + c
+    return out
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 at full size (10 M x 150 bp, device-generated): properties that do not need
+    the oracle at that size --
+      * sharding invariance: one 10 M batch == the sum of four 2.5 M batches (other batch borders,
+        other worklists, other queue interleaving);
+      * idempotence: a second pass doubles every count exactly;
+      * the uniform-geometry fast filter == the general filter (same reads as a ragged batch with
+        explicit device offsets/lengths) == no filter at all, on a 2 M prefix;
+      * the first 200 k reads are bit-exact against the CPU oracle."""
+    import ctypes as C
+    n, L = 10_000_000, 150
+    stride = 3 * ((L + 31) // 32)
+    seed = 20250218
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=n, max_batch_words=16, table_log2_slots=20) as t:
+        d = t.malloc(n * stride * 4 + 64)
+        t.synth_short_device(seed, 0, n, L, d)
+        t.submit(t.device_uniform_batch(d, n, L))
+        t.wait()
+        whole = t.collect()
+        assert sum(sum(v.values()) for v in whole.values()) > 10_000_000  # ~1.5 % repeat reads, ~70-145 windows each
+        t.submit(t.device_uniform_batch(d, n, L))
+        t.wait()
+        assert t.collect() == {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        t.reset_tables()
+        q = n // 4
+        for i in range(4):
+            t.submit(t.device_uniform_batch(d + i * q * stride * 4, q, L))
+            t.wait()
+        assert t.collect() == whole
+        # 2 M prefix: fast filter vs general filter (ragged view of the same words) vs no filter
+        m = 2_000_000
+        t.reset_tables()
+        t.submit(t.device_uniform_batch(d, m, L))
+        t.wait()
+        fast = t.collect()
+        offs = (np.arange(m, dtype=np.uint32) * np.uint32(stride))
+        lens = np.full(m, L, dtype=np.uint32)
+        d_offs, d_lens = t.malloc(m * 4), t.malloc(m * 4)
+        t._chk(t.lib.trew_hip_memcpy_h2d(t.ctx, d_offs, offs.ctypes.data, m * 4), "h2d")
+        t._chk(t.lib.trew_hip_memcpy_h2d(t.ctx, d_lens, lens.ctypes.data, m * 4), "h2d")
+        t.reset_tables()
+        t.submit(capi.Batch(d, m * stride, d_offs, d_lens, 0, 0, m, 1, L))
+        t.wait()
+        assert t.collect() == fast
+        t.free(d_offs)
+        t.free(d_lens)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=m, max_batch_words=16, table_log2_slots=20, flags=T.FLAG_NO_FILTER) as t2:
+        d2 = t2.malloc(m * stride * 4 + 64)
+        t2.synth_short_device(seed, 0, m, L, d2)
+        t2.submit(t2.device_uniform_batch(d2, m, L))
+        t2.wait()
+        assert t2.collect() == fast
+        t2.free(d2)
+    k = 200_000
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=k, max_batch_words=16, table_log2_slots=20) as t3:
+        d3 = t3.malloc(k * stride * 4 + 64)
+        t3.synth_short_device(seed, 0, k, L, d3)
+        t3.submit(t3.device_uniform_batch(d3, k, L))
+        t3.wait()
+        got = t3.collect()
+        t3.free(d3)
+    buf, st, nd = capi.synth_short_ascii(seed, 0, k, L)
+    want, _ = O.run_short_mt_timed(O.OracleParams(), buf, st, nd, os.cpu_count() or 8)
+    assert got == want
+
+
+def test_full_size_properties_pair_and_long():
+    """Configs 3 and 4 at bench size (10 M pairs of 2 x 150 bp; 200 k ONT-like reads = 3.1 Gbases):
+    sharding invariance and idempotence of the tables, and bit-exactness against the oracle on a
+    prefix small enough for the CPU."""
+    L = 150
+    stride = 3 * ((L + 31) // 32)
+    seed = 20250218
+    npairs = 10_000_000
+    with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=2 * npairs, max_batch_words=16, table_log2_slots=20) as t:
+        d = t.malloc(2 * npairs * stride * 4 + 64)
+        t.synth_pair_device(seed, 0, npairs, L, d)
+        t.submit(t.device_uniform_batch(d, 2 * npairs, L))
+        t.wait()
+        whole = t.collect()
+        assert sum(sum(v.values()) for v in whole.values()) > 10_000_000
+        t.reset_tables()
+        q = npairs // 5
+        for i in range(5):
+            t.submit(t.device_uniform_batch(d + 2 * i * q * stride * 4, 2 * q, L))
+            t.wait()
+        assert t.collect() == whole
+        m = 30_000  # pairs checked against the oracle
+        t.reset_tables()
+        t.submit(t.device_uniform_batch(d, 2 * m, L))
+        t.wait()
+        got = t.collect()
+        t.free(d)
+    b1, b2, st, nd = capi.synth_pair_ascii(seed, 0, m, L)
+    assert got == O.run_pair(O.OracleParams(), [b1[s:e + 1] for s, e in zip(st, nd)], [b2[s:e + 1] for s, e in zip(st, nd)])
+
+    nlong = 200_000
+    with T.TrewHip(mode=T.MODE_LONG, slice_length=150, max_batch_reads=nlong, max_batch_words=16, table_log2_slots=20) as t:
+        b, ptrs, bases = t.synth_long_device(seed, 0, nlong)
+        assert bases > 3_000_000_000
+        t.submit(b)
+        t.wait()
+        whole = t.collect()
+        assert sum(sum(v.values()) for v in whole.values()) > 1_000_000
+        t.submit(b)
+        t.wait()
+        assert t.collect() == {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        for p in ptrs:
+            t.free(p)
+        # two halves generated separately (first_read offsets the counter-based generator)
+        t.reset_tables()
+        for first in (0, nlong // 2):
+            b2, ptrs2, _ = t.synth_long_device(seed, first, nlong // 2)
+            t.submit(b2)
+            t.wait()
+            for p in ptrs2:
+                t.free(p)
+        assert t.collect() == whole
