@@ -152,6 +152,25 @@ def main():
                 traffic = round(tj["kernels"][dom]["hbm_bytes_per_launch"])
         except (OSError, KeyError, ValueError):
             traffic = None
+        # VALU occupancy of the dominant kernel from the committed rocprofv3 run of this same command
+        # (profiles/r01/pmc_summary_final.csv + kernel_stats_final.csv): rocprof's VALUBusy definition,
+        # SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), with the profiled average duration
+        valu_busy = None
+        try:
+            if traffic is not None:
+                import csv
+                prof = os.path.join(ROOT, "profiles", "r01")
+                active = dur_ns = None
+                for r in csv.DictReader(open(os.path.join(prof, "pmc_summary_final.csv"))):
+                    if dom in r["kernel"] and r["counter"] == "SQ_ACTIVE_INST_VALU":
+                        active = float(r["avg_per_dispatch"])
+                for r in csv.DictReader(open(os.path.join(prof, "kernel_stats_final.csv"))):
+                    if dom in r["Name"]:
+                        dur_ns = float(r["AverageNs"])
+                if active and dur_ns:
+                    valu_busy = round(active * 4.0 / (256 * 4 * dur_ns * 1e-9 * 2.4e9), 3)
+        except (OSError, KeyError, ValueError):
+            valu_busy = None
         out = {
             "metric": {"short": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
                        "pair": "Gbases/s scanned (short %d %d --paired_end, 2x%d bp)" % (args.min_mer, args.max_mer, L),
@@ -184,7 +203,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
-                "note": "integer-issue bound, not HBM bound (SURVEY 8(d)): %.3g (window,k) evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
+                "valu_busy": valu_busy,
+                "note": "integer-issue bound, not HBM bound (SURVEY 8(d)): valu_busy = share of SIMD cycles issuing VALU work in the committed rocprofv3 PMC run (profiles/r01); %.3g (window,k) evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
                         % (evals / ((f_avg + e_avg) * 1e-3), evals / ((f_avg + e_avg) * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
             },
             "flagged_reads_per_step": int(nflag),
