@@ -27,6 +27,29 @@ VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
 EVALS_PER_150BP_READ = 3220  # (window,k) evaluations per 150-bp read at 5 32
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask and the cgroup CPU quota, not the host's count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(round(quota / period))))
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,11 +239,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         import oracle as O
 
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         op = O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer)
         t.reset_tables()
         if args.mode == "short":
-            m = min(args.cpu_reads, n)
+            # bounded sample, ~10-30 s of CPU work: 250 k reads per usable core
+            m = min(max(args.cpu_reads, cores * 250_000), n)
             buf, st, nd = capi.synth_short_ascii(SEED, 0, m, L)
             want, cpu_dt = O.run_short_mt_timed(op, buf, st, nd, cores)
             t.submit(t.device_uniform_batch(d_words, m, L), 0)

@@ -576,10 +576,12 @@ typedef struct {
     const char *buf;
     const int64_t *st, *nd;
     int64_t n;
+    const trew_oracle_params *p;
 } mt_arg;
 
 static void *mt_worker(void *a_) {
     mt_arg *a = (mt_arg *) a_;
+    a->c = trew_oracle_new(a->p); /* per-thread tables are allocated and cleared by the thread that uses them */
     trew_oracle_add_short(a->c, a->buf, a->st, a->nd, a->n);
     return NULL;
 }
@@ -594,7 +596,8 @@ trew_oracle_ctx *trew_oracle_run_short_mt(const trew_oracle_params *p, const cha
         int64_t lo = per * t, hi = lo + per;
         if (lo > n) lo = n;
         if (hi > n) hi = n;
-        args[t].c = trew_oracle_new(p);
+        args[t].c = NULL;
+        args[t].p = p;
         args[t].buf = buf;
         args[t].st = st + lo;
         args[t].nd = nd + lo;
