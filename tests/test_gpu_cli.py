@@ -130,3 +130,23 @@ def test_cli_rejects_long_read_in_short_mode(tmp_path):
     r = subprocess.run([TREW, "short", "5", "32", a], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1
     assert "This mode is designed for short-read sequencing. Please use 'trew long'." in r.stderr
+
+
+def test_cli_bgzf_input(tmp_path):
+    """Block-gzip (bgzip) input goes through the parallel BGZF reader: same output as the plain file,
+    single and paired, with members cut at arbitrary places (lines and records span members)."""
+    from test_bgzf_cpu import write_bgzf
+
+    b1, b2, st, nd = capi.synth_pair_ascii(20250218, 0, 40000, 150)
+    r1 = [b1[s:e + 1] for s, e in zip(st, nd)]
+    r2 = [b2[s:e + 1] for s, e in zip(st, nd)]
+    plain1, plain2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    write_fastq(plain1, r1)
+    write_fastq(plain2, r2)
+    z1, z2 = str(tmp_path / "r1.fastq.gz"), str(tmp_path / "r2.fastq.gz")
+    write_bgzf(z1, open(plain1, "rb").read())
+    write_bgzf(z2, open(plain2, "rb").read(), block=12345)
+    want_single = expected([(z1, O.run_short(O.OracleParams(), r1))], 5)
+    assert run("short", "5", "32", z1, "-t", "4") == want_single
+    want_pair = expected([(z1, O.run_pair(O.OracleParams(), r1, r2))], 5)
+    assert run("short", "5", "32", "--paired_end", "--fq1", z1, "--fq2", z2, "-t", "4") == want_pair

@@ -18,6 +18,7 @@
 #include <mutex>
 #include <thread>
 
+#include "bgzf_reader.hpp"
 #include "trew_host.hpp"
 
 namespace trew_host {
@@ -35,9 +36,17 @@ struct FileReader {
     bool is_gz = false;
     FILE *fp = nullptr;
     gzFile gz_fp = nullptr;
-    int read(char *buffer, int length) { return is_gz ? gzread(gz_fp, buffer, (unsigned) length) : (int) fread(buffer, 1, (size_t) length, fp); }
-    bool eof() { return is_gz ? gzeof(gz_fp) != 0 : feof(fp) != 0; }
+    BgzfReader *bgzf = nullptr;  // block-gzip input: members inflated on several threads
+    int read(char *buffer, int length) {
+        if (bgzf) return bgzf->read(buffer, length);
+        return is_gz ? gzread(gz_fp, buffer, (unsigned) length) : (int) fread(buffer, 1, (size_t) length, fp);
+    }
+    bool eof() {
+        if (bgzf) return bgzf->eof();
+        return is_gz ? gzeof(gz_fp) != 0 : feof(fp) != 0;
+    }
     const char *error() {
+        if (bgzf) return bgzf->error();
         if (is_gz) {
             int err_num;
             return gzerror(gz_fp, &err_num);
@@ -45,16 +54,28 @@ struct FileReader {
         return strerror(errno);
     }
     void close() {
-        if (is_gz)
+        if (bgzf)
+            delete bgzf;
+        else if (is_gz)
             gzclose(gz_fp);
         else
             fclose(fp);
+        bgzf = nullptr;
     }
 };
 
 static FileReader open_reader(const char *file_name, bool is_gz) {
     FileReader r;
     r.is_gz = is_gz;
+    if (is_gz && BgzfReader::sniff(file_name)) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        r.bgzf = new BgzfReader(file_name, (int) std::min(8u, std::max(2u, hw / 2)));
+        if (!r.bgzf->ok()) {
+            fprintf(stderr, "File open failed: %s\n", file_name);
+            exit(EXIT_FAILURE);
+        }
+        return r;
+    }
     if (is_gz) {
         r.gz_fp = gzopen(file_name, "r");
         if (!r.gz_fp) {  // kmer.cpp:1288-1289
