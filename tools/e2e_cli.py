@@ -18,3 +18,23 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for t in (2, 4, 8, 16):
     r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", path, "-t", str(t), "--stats"], capture_output=True, text=True)
     print("threads", t, r.stderr.strip().splitlines()[-1] if r.stderr else r.returncode)
+
+# the same file as plain gzip (one member: gzread on one thread, as the reference does) and as BGZF
+# (independent 64 KiB members: inflated on several threads by host/bgzf_reader.hpp)
+import gzip, zlib, struct
+sub = rec[: n // 4].tobytes()  # 2 M reads: zlib at level 1 is slow enough already
+gz = "/tmp/e2e_plain.fastq.gz"
+with gzip.open(gz, "wb", compresslevel=1) as f:
+    f.write(sub)
+bg = "/tmp/e2e_bgzf.fastq.gz"
+with open(bg, "wb") as f:
+    for i in list(range(0, len(sub), 0xFF00)) + [None]:
+        c = b"" if i is None else sub[i:i + 0xFF00]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(c) + co.flush()
+        f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(body) + 8 - 1))
+        f.write(body)
+        f.write(struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c) & 0xFFFFFFFF))
+for name, p in (("plain gzip", gz), ("BGZF", bg)):
+    r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", p, "-t", "8", "--stats"], capture_output=True, text=True)
+    print(name, r.stderr.strip().splitlines()[-1] if r.stderr else r.returncode)
