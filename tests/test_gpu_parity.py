@@ -631,3 +631,65 @@ def test_full_size_properties_pair_and_long():
             for p in ptrs2:
                 t.free(p)
         assert t.collect() == whole
+
+
+def _fixed_len_reads(rnd, count, n):
+    """Like _fuzz_reads, every read exactly n bases long."""
+    from helpers import mutate, periodic
+
+    out = []
+    for _ in range(count):
+        kind = rnd.random()
+        if kind < 0.35:
+            s = "".join(rnd.choice("ACGT") for _ in range(n))
+            if rnd.random() < 0.2:
+                s = mutate(s, rnd, p_sub=0, p_n=rnd.choice([0.005, 0.02, 0.2]))
+        elif kind < 0.42:
+            s = "".join(rnd.choice("AT") for _ in range(n))
+        else:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 70)))
+            s = periodic(unit, n, rnd.randint(0, 11))
+            s = mutate(s, rnd, p_sub=rnd.choice([0, 0.01, 0.05, 0.2]), p_n=rnd.choice([0, 0, 0, 0.01, 0.1]))
+            if rnd.random() < 0.3:
+                cut = rnd.randint(0, n)
+                u2 = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(2, 40)))
+                s = s[:cut] + periodic(u2, n - cut)
+        s = s[:n]
+        s += "".join(rnd.choice("ACGT") for _ in range(n - len(s)))
+        out.append(s.encode())
+    return out
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_FUZZ_SEEDS", "40"))))
+def test_fuzz_uniform_batches(seed):
+    """Equal-length batches submitted WITHOUT offsets/lengths (uniform_length set): the prefilter takes
+    its uniform-geometry fast path (scalar COUNT/masks/thresholds, N reads set aside) -- random
+    lengths, k ranges, baselines, motifs, N densities; short and pair mode against the oracle, and the
+    same words as a ragged batch (general path) for equality of the two paths."""
+    import random
+
+    rnd = random.Random(5000 + seed)
+    mn = rnd.choice([3, 4, 5, 6, 9, 17])
+    mx = max(mn, rnd.choice([mn, mn + 1, 12, 20, 31, 32, 33, 48, 63, 64]))
+    low = rnd.choice([0.5, 0.3, 0.51, 2 / 3, 0.75, 1.0])
+    high = max(low, rnd.choice([0.8, 0.6, 0.9, 1.0]))
+    kw = dict(min_mer=mn, max_mer=mx, low=low, high=high)
+    p = O.OracleParams(**kw)
+    n = rnd.choice([rnd.randint(2 * mn, 64), rnd.randint(64, 159), 150, 151, rnd.randint(160, 319), rnd.randint(320, 700)])
+    count = 600  # even: also used as 300 pairs
+    reads = _fixed_len_reads(rnd, count, n)
+    words, offs, lens = capi.pack_reads(reads)
+    stride = 3 * ((n + 31) // 32)
+    assert len(words) == count * stride and int(offs[1]) == stride
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    uni = capi.Batch(words.ctypes.data, len(words), None, None, n, stride, count, 0, n)
+    for mode, want in ((T.MODE_SHORT, O.run_short(p, reads)), (T.MODE_PAIR, O.run_pair(p, reads[0::2], reads[1::2]))):
+        with T.TrewHip(mode=mode, max_batch_reads=count + 8, max_batch_words=len(words) + 64, **kw) as t:
+            t.submit(uni)
+            t.wait()
+            got = t.collect()
+            assert got == want, ("uniform", mode, n, kw)
+            t.reset_tables()
+            t.submit(t.host_batch(words, offs, lens))
+            t.wait()
+            assert t.collect() == want, ("ragged", mode, n, kw)
