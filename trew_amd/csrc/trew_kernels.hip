@@ -789,7 +789,9 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 //   canon [cap]  WT   per run (fast path) or per window (fallback); WT = u64 (k <= 32) or u128
 struct ExactSmem {
     u32 cap, rawwords;
-    u32 s0;  // first base of the current segment within the staged bases
+    u32 s0;         // first base of the current segment within the staged bases
+    u32 rs, rnw;    // the same segment in the read's packed triples: first base, triples of the read
+    const u32 *rw;  // the read's triples (LDS copy or global), nullptr when unknown
 };
 __host__ __device__ inline u32 exact_rangewords(u32 cap) { return cap / 32 + 2; }  // words of one staged range (+ read-ahead)
 
@@ -852,6 +854,9 @@ __device__ __forceinline__ ExactSmem uni(ExactSmem sm) {
     sm.cap = rfl(sm.cap);
     sm.rawwords = rfl(sm.rawwords);
     sm.s0 = rfl(sm.s0);
+    sm.rs = rfl(sm.rs);
+    sm.rnw = rfl(sm.rnw);
+    sm.rw = rfl_ptr(sm.rw);
     return sm;
 }
 __device__ __forceinline__ DevTable uni(DevTable T) {
@@ -921,14 +926,20 @@ __attribute__((noinline)) __device__ void stage_bases(ExactSmem sm, ReadRef rd, 
 // first base of staged range r
 __device__ __forceinline__ u32 range_base(ExactSmem sm, u32 r) { return r * 32u * exact_rangewords(sm.cap); }
 // the segment [s, s+L) of a read whose bases are staged as range r: a view, nothing moves
-__device__ __forceinline__ ExactSmem view_segment(ExactSmem sm, u32 r, u32 s) {
+__device__ __forceinline__ ExactSmem view_segment(ExactSmem sm, u32 r, u32 s, const ReadRef &rd) {
     sm.s0 = range_base(sm, r) + s;
+    sm.rs = s;
+    sm.rnw = rd.nw;
+    sm.rw = rd.w;
     return sm;
 }
 // long mode: stage one slice at base 0 and look at it
 __device__ __forceinline__ ExactSmem load_segment(ExactSmem sm, ReadRef rd, u32 s, u32 L) {
     stage_bases(sm, rd, s, L, 0);
     sm.s0 = 0;
+    sm.rs = s;
+    sm.rnw = rd.nw;
+    sm.rw = rd.w;
     return sm;
 }
 
@@ -1175,6 +1186,37 @@ __attribute__((noinline)) __device__ KStat<WT> eval_k(ExactSmem sm, int L, int k
     m5 &= kmask<WT>(k);
     u32 b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
     __syncthreads();  // previous users of the LDS arrays are done
+    if (need == 0.0 && sm.rw != nullptr && k < 64) {
+        // No pruning wanted (record / k_mer_target): the window masks of this one k come straight from
+        // the packed planes, lane j building 32 windows at once -- E = bases i and i+k agree, V = the
+        // L-k+1 windows of an N-free segment -- instead of a walk over the windows.  A segment with an
+        // N keeps the general walk below.
+        const u32 segw = ((u32) L + 31u) >> 5;
+        ReadRef rr;
+        rr.w = sm.rw;
+        rr.nw = sm.rnw;
+        rr.len = 0;
+        u32 lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, nm[3] = {0, 0, 0};
+        if (lane < segw) load_planes<3>(rr, sm.rs + 32u * lane, lo, hi, nm);
+        const int lbits = L - 32 * (int) lane;
+        const u32 lm = lbits >= 32 ? 0xffffffffu : (lbits <= 0 ? 0u : ((1u << lbits) - 1u));
+        if (!__any((nm[0] & lm) != 0u)) {
+            const bool big = k >= 32;
+            const u32 ks = (u32) k & 31u;
+            const u32 slo = alignbit(big ? lo[2] : lo[1], big ? lo[1] : lo[0], ks);
+            const u32 shi = alignbit(big ? hi[2] : hi[1], big ? hi[1] : hi[0], ks);
+            const u32 e = ~((lo[0] ^ slo) | (hi[0] ^ shi));
+            const int wbits = W - 32 * (int) lane;
+            const u32 v = wbits >= 32 ? 0xffffffffu : (wbits <= 0 ? 0u : ((1u << wbits) - 1u));
+            if (lane < 2u * ((u32) rounds + 1u)) {  // including the terminating zero word
+                ((u32 *) sm_vmask(sm))[lane] = v;
+                ((u32 *) sm_emask(sm))[lane] = e & v;
+            }
+            __syncthreads();
+            PH_ADD(PH_EVALK_A, t_ph);
+            return eval_runs<WT>(sm, W, k);
+        }
+    }
     for (int r = 0; r < rounds; r++) {
         const u32 i = (u32) r * 64u + lane;
         bool valid = false, eq = false, p1 = false, p2 = false, p3 = false;
@@ -1687,7 +1729,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     Decision<WT> left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
     if (sL.valid || sW.valid) stage_bases(sm, rd, 0, (u32) n, 0);  // the whole read, once; segments are views
     if (sL.valid) {
-        sm = view_segment(sm, 0, sL.start);
+        sm = view_segment(sm, 0, sL.start, rd);
         LaneMasks<NWB> mL, mR;
         const bool both = P.max_mer - P.min_mer < 32;  // the k range fits half a wave: both halves in one pass
         if (UB) {
@@ -1701,7 +1743,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
         const bool halves = UB && both;
         if (halves) mR = mL;  // the right half's bounds sit in lanes 32..63 of the same registers
         left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL, 0, halves ? 32 : 64);
-        sm = view_segment(sm, 0, sR.start);
+        sm = view_segment(sm, 0, sR.start, rd);
         right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR, halves ? 32 : 0, halves ? 32 : 64);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
@@ -1723,7 +1765,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
             const bool rec_h = left.kh > 0 && !tgt_h;  // temp_result_left.first -> forward.first (kmer.cpp:132-134)
             const bool rec_l = left.kl > 0 && !tgt_l;
             if (rec_h || rec_l) {
-                sm = view_segment(sm, 0, sL.start);
+                sm = view_segment(sm, 0, sL.start, rd);
                 if (rec_h && rec_l && left.kh == left.kl) {
                     record<WT>(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
                 } else {
@@ -1732,7 +1774,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
                 }
             }
             if (tgt_h || tgt_l) {
-                sm = view_segment(sm, 0, 0);
+                sm = view_segment(sm, 0, 0, rd);
                 if (tgt_h && tgt_l && left.kh == left.kl) {
                     target<WT>(sm, P, T, n, left.kh, true, true);
                 } else {
@@ -1745,7 +1787,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     const bool hh = left.kh == 0 && right.kh == 0;  // kmer.cpp:165-166
     const bool lh = left.kl == 0 && right.kl == 0;
     if (sW.valid && (hh || lh)) {  // kmer.cpp:168-171
-        sm = view_segment(sm, 0, 0);
+        sm = view_segment(sm, 0, 0, rd);
         LaneMasks<NWB> mW;
         if (UB) lane_bounds<NWB>(rd, 0, n, P.min_mer, P.max_mer, mW);
         const Decision<WT> w = decide<NW, WT>(sm, P, n, sW.kmin, sW.kmax, ~0ull, mW);
@@ -1962,7 +2004,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
         const Segment sg = seg_of(slot);
         const ReadRef &r = sg.mate ? r1 : r0;
-        const ExactSmem sv = view_segment(sm, sg.mate, sg.start);
+        const ExactSmem sv = view_segment(sm, sg.mate, sg.start, r);
         LaneMasks<NWB> m;
         if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
         const Decision<WT> d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
@@ -2003,7 +2045,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             }
             if (mp | mc) {
                 const Segment sg = seg_of(slot);
-                const ExactSmem sv = view_segment(sm, sg.mate, sg.start);
+                const ExactSmem sv = view_segment(sm, sg.mate, sg.start, sg.mate ? r1 : r0);
                 const KStat<WT> st = uni(eval_k<WT>(sv, (int) sg.len, k, 0.0));
                 if (mp) emit_k<WT>(sv, T, st.n_items, k, mp, false);
                 if (mc) emit_k<WT>(sv, T, st.n_items, k, mc, true);
@@ -2123,6 +2165,8 @@ __global__ __launch_bounds__(64, (NW >= 10 ? 4 : 6)) void exact_kernel(DevParams
     sm.cap = cap;
     sm.rawwords = rawwords;
     sm.s0 = 0;
+    sm.rs = sm.rnw = 0;
+    sm.rw = nullptr;
     u32 n = wl_count[0];
     n = n < wl_cap ? n : wl_cap;
 #ifdef TREW_PHASE_PROFILE
