@@ -53,7 +53,8 @@ enum {
 enum {
     TREW_FLAG_NO_FILTER = 1, /* skip the bucket-bound prefilter: every k is a candidate (exact path only) */
     TREW_FLAG_DEBUG_NO_EMIT = 2, /* timing experiments only: drop every table update (results are empty) */
-    TREW_FLAG_DEBUG_NO_KLOOP = 4 /* timing experiments only: prefilter without its k loop (nothing is flagged) */
+    TREW_FLAG_DEBUG_NO_KLOOP = 4, /* timing experiments only: prefilter without its k loop (nothing is flagged) */
+    TREW_FLAG_DEBUG_POISON_LDS = 32 /* tests: the exact kernel starts from garbage-filled LDS */
 };
 
 /* Replaces the eight configuration globals MIN_MER ... HIGH_BASELINE

@@ -693,3 +693,30 @@ def test_fuzz_uniform_batches(seed):
             t.submit(t.host_batch(words, offs, lens))
             t.wait()
             assert t.collect() == want, ("ragged", mode, n, kw)
+
+
+def test_results_do_not_depend_on_lds_residue():
+    """Dynamic LDS is not cleared between kernels.  With FLAG_DEBUG_POISON_LDS the exact kernel starts
+    from garbage-filled LDS; every mode must still match the oracle (TREW_EXTRA_FLAGS=32 runs the
+    whole suite that way)."""
+    import random
+
+    rnd = random.Random(77)
+    p = O.OracleParams()
+    reads = _fuzz_reads(rnd, 400, 300) + edge_reads(3)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, flags=T.FLAG_DEBUG_POISON_LDS) as t:
+        t.submit_reads(reads)
+        t.wait()
+        assert t.collect() == O.run_short(p, reads)
+    r1 = _fuzz_reads(rnd, 200, 300)
+    r2 = [_revcomp(r) if rnd.random() < 0.6 else x for r, x in zip(r1, _fuzz_reads(rnd, 200, 300))]
+    both = [x for pr in zip(r1, r2) for x in pr]
+    with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=len(both) + 8, max_batch_words=1 << 22, flags=T.FLAG_DEBUG_POISON_LDS) as t:
+        t.submit_reads(both)
+        t.wait()
+        assert t.collect() == O.run_pair(p, r1, r2)
+    lr = [r for r in _fuzz_reads(rnd, 150, 4000) if len(r) >= 150]
+    with T.TrewHip(mode=T.MODE_LONG, slice_length=150, max_batch_reads=len(lr) + 8, max_batch_words=1 << 22, flags=T.FLAG_DEBUG_POISON_LDS) as t:
+        t.submit_reads(lr)
+        t.wait()
+        assert t.collect() == O.run_long(O.OracleParams(slice_len=150), lr)

@@ -7,6 +7,7 @@ only binds the C ABI for tests and benchmarks.
 from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
     FLAG_NO_FILTER,
+    FLAG_DEBUG_POISON_LDS,
     MODE_LONG,
     MODE_PAIR,
     MODE_SEGMENT,

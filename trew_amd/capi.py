@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("TREW_HIP_LIB") or os.path.join(_HERE, "lib", "libtrew
 
 MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
 FLAG_NO_FILTER = 1
+FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (tests)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
 
 # every symbol include/trew_hip.h declares
@@ -192,6 +193,7 @@ class TrewHip:
     def __init__(self, mode=MODE_SHORT, min_mer=5, max_mer=32, low=0.5, high=0.8, slice_length=150, device=0,
                  n_slots=2, max_batch_words=1 << 22, max_batch_reads=1 << 18, table_log2_slots=20, flags=0):
         self.lib = load()
+        flags |= int(os.environ.get("TREW_EXTRA_FLAGS", "0"))  # e.g. 32 = FLAG_DEBUG_POISON_LDS for a whole test run
         self.params = Params(min_mer, max_mer, low, high, slice_length, mode, device, n_slots, max_batch_words,
                              max_batch_reads, table_log2_slots, flags)
         self.ctx = C.c_void_p()

@@ -28,6 +28,9 @@
 
 #include <algorithm>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "trew_common.hpp"
 #include "trew_launch.hpp"
 #include "trew_synth.hpp"
@@ -2174,6 +2177,11 @@ __global__ __launch_bounds__(64, (NW >= 10 ? 4 : 6)) void exact_kernel(DevParams
     __syncthreads();
 #endif
     PH_T0(t_total);
+    if (P.flags & TREW_FLAG_DEBUG_POISON_LDS) {  // tests: nothing may depend on what a previous kernel left in LDS
+        const u32 nb = exact_lds_bytes(cap, rawwords, sizeof(WT));
+        for (u32 i = lane_id() * 4u; i < nb; i += 256u) *(u32 *) (lds0() + i) = 0xA5C3F00Du ^ (i * 2654435761u);
+        __syncthreads();
+    }
     cache_clear(sm);
     // dynamic self-scheduling: reads differ 10x in cost, so waves pull work from device counters
     // instead of a static stride.  One returning atomic on a single word saturates at ~88
