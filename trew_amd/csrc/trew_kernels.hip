@@ -1652,19 +1652,15 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
                 // instantiation's NW covers more bits than this batch's segments need
                 const int nq_all = (NWB + 1) / 2, nq_fit = (int) (sm.cap / 64u) + 1;
                 const int nq = nq_all < nq_fit ? nq_all : nq_fit;
+                if ((int) lane_id() == src) {  // the lane that owns this k stores its masks itself: no broadcast needed
 #pragma unroll
-                for (int q = 0; q < nq_all; q++) {
-                    if (q >= nq) break;
-                    const u32 v0 = (u32) __builtin_amdgcn_readlane((int) M.V[2 * q], src);
-                    const u32 e0 = (u32) __builtin_amdgcn_readlane((int) M.E[2 * q], src);
-                    const u32 v1 = 2 * q + 1 < NWB ? (u32) __builtin_amdgcn_readlane((int) M.V[2 * q + 1 < NWB ? 2 * q + 1 : 0], src) : 0u;
-                    const u32 e1 = 2 * q + 1 < NWB ? (u32) __builtin_amdgcn_readlane((int) M.E[2 * q + 1 < NWB ? 2 * q + 1 : 0], src) : 0u;
-                    if (lane_id() == 0) {
-                        vm[q] = ((u64) v1 << 32) | v0;
-                        em[q] = ((u64) e1 << 32) | e0;
+                    for (int q = 0; q < nq_all; q++) {
+                        if (q >= nq) break;
+                        const u32 v1 = 2 * q + 1 < NWB ? M.V[2 * q + 1 < NWB ? 2 * q + 1 : 0] : 0u;
+                        const u32 e1 = 2 * q + 1 < NWB ? M.E[2 * q + 1 < NWB ? 2 * q + 1 : 0] : 0u;
+                        vm[q] = ((u64) v1 << 32) | M.V[2 * q];
+                        em[q] = ((u64) e1 << 32) | M.E[2 * q];
                     }
-                }
-                if (lane_id() == 0) {
                     vm[nq] = 0;
                     em[nq] = 0;
                 }
