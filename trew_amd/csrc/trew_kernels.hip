@@ -1991,6 +1991,8 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     // chain decided (slot s cached in lane s)
     u32 dc_k = 0, dc_have = 0;
     WT dc_sh = 0, dc_sl = 0;
+    LaneMasks<NWB> mp;  // bounds of both halves of mate mp_pair
+    int mp_pair = -1;
     auto seg_decide = [&](int slot) {
         if ((dc_have >> slot) & 1u) {
             Decision<WT> d;
@@ -2004,9 +2006,21 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         const Segment sg = seg_of(slot);
         const ReadRef &r = sg.mate ? r1 : r0;
         const ExactSmem sv = view_segment(sm, sg.mate, sg.start, r);
-        LaneMasks<NWB> m;
-        if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
-        const Decision<WT> d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        Decision<WT> d;
+        if (UB && slot < 4 && P.max_mer - P.min_mer < 32) {
+            // the two halves of one mate share a lane pass (lanes 0..31 / 32..63); the chains visit them back to back
+            const int pr = slot >> 1;
+            if (mp_pair != pr) {
+                const Segment a = seg_of(2 * pr), b = seg_of(2 * pr + 1);
+                lane_bounds_pair<NWB>(r, a.start, (int) a.len, b.start, (int) b.len, P.min_mer, P.max_mer, mp);
+                mp_pair = pr;
+            }
+            d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, mp, (slot & 1) ? 32 : 0, 32);
+        } else {
+            LaneMasks<NWB> m;
+            if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
+            d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
+        }
         if ((int) lane == slot) {
             dc_k = (u32) d.kh | ((u32) d.kl << 8);
             dc_sh = d.sh;
