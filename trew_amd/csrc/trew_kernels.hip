@@ -18,7 +18,7 @@
 //     k_mer_check / k_mer_target / buffer_task* exactly, but only for candidate
 //     k: the same bucket bound for all k at once (lane = k) prunes against the running
 //     thresholds; survivors are split into runs of adjacent same-class windows (Lemma A),
-//     one canonical rotation per run, runs merged by readlane broadcasts; MAX_SEQ's
+//     one canonical rotation per run, runs merged per class (ballot + DPP sum); MAX_SEQ's
 //     "first class to reach the maximum" tie-break (strict '<' at kmer.cpp:2202) is the
 //     class whose last window comes first.  Histograms go through a wave-private LDS count
 //     cache into a device-resident open-addressing table with 64-bit CAS keys.
@@ -27,9 +27,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-
-#include <cstdio>
-#include <cstdlib>
 
 #include "trew_common.hpp"
 #include "trew_launch.hpp"
@@ -787,7 +784,7 @@ __device__ __forceinline__ void table_add(DevTable T, int table, int k, u128 wor
 //   raw   [4][rawwords] u32  packed triples of the chunk's reads (or of the two mates), staged once
 //   cnt   [cap] u16  class size at the class's first item, else 0
 //   start [cap] u16  first window of each run
-//   intent [32] u32  deferred histogram emissions of the pair driver
+//   intent [32] u32  per-chunk read descriptors of the short/segment driver (`meta`)
 //   ckey/cpart/ccnt [kCacheSlots]  the wave's private count cache (see cached_add)
 //   canon [cap]  WT   per run (fast path) or per window (fallback); WT = u64 (k <= 32) or u128
 struct ExactSmem {
