@@ -38,7 +38,7 @@ struct Slot {
     u64 n_units = 0;
 };
 
-std::string g_init_error;
+thread_local std::string g_init_error;  // trew_hip_init failures before a context exists (read back on the same thread)
 constexpr size_t kWlCountBytes = (32 + 8 * 32) * 4;  // [0] worklist size, then 8 queue heads on separate 128-B lines
 
 }  // namespace

@@ -2486,9 +2486,10 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     }
 #undef TREW_PICK_MODE
     // the occupancy query is not free: remember the last answer
-    static kern_t cached_fn = nullptr;
-    static u32 cached_lds = 0;
-    static int cached_per_cu = 0;
+    // (per host thread: the packer threads of the CLI submit concurrently on their own slots)
+    static thread_local kern_t cached_fn = nullptr;
+    static thread_local u32 cached_lds = 0;
+    static thread_local int cached_per_cu = 0;
     int per_cu = 8;
     if (cached_fn == fn && cached_lds == lds) {
         per_cu = cached_per_cu;
