@@ -994,13 +994,11 @@ __device__ __forceinline__ WT min_rotation(WT w, int k) {
     return ans;
 }
 // reverse the 32 2-bit groups of a 64-bit word and complement them
+// (bit reversal is one v_bfrev per half; it also swaps the two bits of every group, which one more step undoes)
 __device__ __forceinline__ u64 revcomp_groups64(u64 x) {
-    x = (x >> 32) | (x << 32);
-    x = ((x >> 16) & 0x0000ffff0000ffffull) | ((x & 0x0000ffff0000ffffull) << 16);
-    x = ((x >> 8) & 0x00ff00ff00ff00ffull) | ((x & 0x00ff00ff00ff00ffull) << 8);
-    x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
-    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-    return ~x;
+    const u32 lo = __brev((u32) (x >> 32)), hi = __brev((u32) x);  // reversed halves, swapped
+    const u32 l2 = ((lo >> 1) & 0x55555555u) | ((lo & 0x55555555u) << 1), h2 = ((hi >> 1) & 0x55555555u) | ((hi & 0x55555555u) << 1);
+    return ~(((u64) h2 << 32) | l2);
 }
 // reverse_complement_64(x) >> 2*(32-k), kmer.cpp:47-54 / 1987
 __device__ __forceinline__ u64 revcomp(u64 x, int k) { return revcomp_groups64(x) >> (2 * (32 - k)); }
