@@ -1848,12 +1848,35 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     if (snum <= 0) return;  // read_fastq_long_thread drops reads shorter than SLICE_LENGTH (kmer.cpp:1184)
     const int mid = (snum + 1) / 2, bonus = len % SL;
     const u64 allk = all_k_mask(P.min_mer, P.max_mer);
-    auto slice_decide = [&](int t, u64 cand) {
+    // bounds of two neighbouring slices share one lane pass (lanes 0..31 / 32..63) when the k range fits
+    // half a wave: a walk that continues finds the next slice's bounds already there
+    constexpr int NS = NW > 5 ? 5 : NWB;
+    LaneMasks<NS> mp;
+    int mp_lo = 0, mp_hi = 0;  // slices whose bounds sit in the low / high half of mp (0: none)
+    auto slice_decide = [&](int t, u64 cand, int dir) {
         u32 st, sl;
         long_slice(t, mid, bonus, SL, st, sl);
         sm = load_segment(sm, rd, st, sl);
         if (NW > 5 && sl <= 159u) {  // every slice but the middle one is SLICE_LENGTH long: half the mask words
-            constexpr int NS = NW > 5 ? 5 : NWB;
+            if (P.max_mer - P.min_mer < 32) {
+                if (t != mp_lo && t != mp_hi) {
+                    const int tn = t + dir;
+                    u32 stn = st, sln = sl;
+                    int other = 0;
+                    if (tn >= 1 && tn <= snum) {
+                        long_slice(tn, mid, bonus, SL, stn, sln);
+                        if (sln <= 159u) other = tn;
+                    }
+                    if (!other) {
+                        stn = st;
+                        sln = sl;
+                    }
+                    lane_bounds_pair<NS>(rd, st, (int) sl, stn, (int) sln, P.min_mer, P.max_mer, mp);
+                    mp_lo = t;
+                    mp_hi = other;
+                }
+                return decide<(NW > 5 ? 5 : NW), WT>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, mp, t == mp_lo ? 0 : 32, 32);
+            }
             LaneMasks<NS> m5;
             lane_bounds<NS>(rd, st, (int) sl, P.min_mer, P.max_mer, m5);
             return decide<(NW > 5 ? 5 : NW), WT>(sm, P, (int) sl, P.min_mer, P.max_mer, cand, m5);
@@ -1869,7 +1892,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     // decisions of the first 64 slices, one per lane (kh | kl << 8), so that pass 2 does not decide them again
     u32 dcache = 0;
     for (int ti = 1; ti <= snum && (!rend[0] || !rend[1]); ti++) {
-        const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+        const Decision<WT> d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk), 1);
         if ((int) lane_id() == ti - 1) dcache = (u32) d.kh | ((u32) d.kl << 8);
         const int tk[2] = {d.kh, d.kl};
 #pragma unroll
@@ -1903,7 +1926,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                     sm = load_segment(sm, rd, st, sl);
                 }
             } else {
-                d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk));
+                d = slice_decide(ti, ti == 1 ? ~0ull : (ti == snum ? ~0ull : allk), 1);
             }
             const bool rh = ti <= last_rec[0] && d.kh > 0, rl = ti <= last_rec[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl && canon_h == canon_l) {
@@ -1920,7 +1943,7 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         kmer[0] = kmer[1] = 0;
         rend[0] = rend[1] = false;
         for (int tj = snum; (!rend[0] || !rend[1]) && tj >= 1; tj--) {
-            const Decision<WT> d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk));
+            const Decision<WT> d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk), -1);
             const bool rh = !rend[0] && d.kh > 0, rl = !rend[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl) {
                 record<WT>(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
