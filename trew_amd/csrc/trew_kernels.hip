@@ -803,8 +803,9 @@ __host__ __device__ inline u32 exact_lds_precache(u32 cap, u32 rawwords) {  // e
 __host__ __device__ inline u32 exact_lds_fixed(u32 cap, u32 rawwords) {  // everything before canon[], 16-byte aligned
     return exact_lds_precache(cap, rawwords) + kCacheSlots * 16u;
 }
+constexpr u32 kSaveItems = 16, kSaveSlots = 6;  // pair driver: class tables kept per slot between decide and flush
 __host__ __device__ inline u32 exact_lds_bytes(u32 cap, u32 rawwords, u32 wordbytes) {
-    return exact_lds_fixed(cap, rawwords) + cap * wordbytes + 16;
+    return exact_lds_fixed(cap, rawwords) + cap * wordbytes + 16 + kSaveSlots * kSaveItems * (wordbytes + 2u);
 }
 
 __device__ __forceinline__ unsigned char *lds0() {
@@ -849,6 +850,10 @@ __device__ __forceinline__ u32 *sm_cpart(ExactSmem sm) { return (u32 *) (sm_ckey
 __device__ __forceinline__ u32 *sm_ccnt(ExactSmem sm) { return sm_cpart(sm) + kCacheSlots; }
 template <typename WT>
 __device__ __forceinline__ WT *sm_canon(ExactSmem sm) { return (WT *) (lds0() + exact_lds_fixed(sm.cap, sm.rawwords)); }
+template <typename WT>
+__device__ __forceinline__ WT *sm_save_canon(ExactSmem sm) { return sm_canon<WT>(sm) + sm.cap + 16 / sizeof(WT); }  // [kSaveSlots][kSaveItems]
+template <typename WT>
+__device__ __forceinline__ unsigned short *sm_save_cnt(ExactSmem sm) { return (unsigned short *) (sm_save_canon<WT>(sm) + kSaveSlots * kSaveItems); }
 
 __device__ __forceinline__ ExactSmem uni(ExactSmem sm) {
     sm.cap = rfl(sm.cap);
@@ -1579,6 +1584,8 @@ template <typename WT>
 struct Decision {
     int kh, kl;   // target_k_high / target_k_low
     WT sh, sl;    // MAX_SEQ at those k (repeat_seq, kmer.cpp:2260-2262)
+    int ek;       // k of the last class count whose canon[] / cnt[] are still in LDS (0: none)
+    u32 en;       // its number of items
 };
 
 // bits j-1 for every multiple j <= 64 of k
@@ -1600,6 +1607,8 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     PH_T0(t_ph);
     d.kh = d.kl = 0;
     d.sh = d.sl = 0;
+    d.ek = 0;
+    d.en = 0;
     double tf_low = 0.0, tf_high = 0.0;
     // closed_*: bit k-1 set <=> k is a multiple of a k already accepted in that loop.  Such a k is
     // never accepted and never moves the running frequency (kmer.cpp:2225-2236).
@@ -1665,6 +1674,8 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
         } else {
             st = uni(eval_k<WT>(sm, L, k, need));
         }
+        d.ek = st.pruned ? 0 : k;
+        d.en = st.n_items;
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
         if (is_homopolymer<WT>(st.maxseq, k)) continue;
@@ -1720,7 +1731,7 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
     const Segment sL = get_segment(TREW_MODE_SHORT, 0, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sR = get_segment(TREW_MODE_SHORT, 1, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
     const Segment sW = get_segment(TREW_MODE_SHORT, 2, rd.len, 0, P.min_mer, P.max_mer, P.slice_len);
-    Decision<WT> left = {0, 0, 0, 0}, right = {0, 0, 0, 0};
+    Decision<WT> left = {0, 0, 0, 0, 0, 0}, right = {0, 0, 0, 0, 0, 0};
     if (sL.valid || sW.valid) stage_bases(sm, rd, 0, (u32) n, 0);  // the whole read, once; segments are views
     if (sL.valid) {
         sm = view_segment(sm, 0, sL.start, rd);
@@ -2007,7 +2018,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     auto seg_of = [&](int slot) { return get_segment(TREW_MODE_PAIR, slot, (u32) n1, (u32) n2, P.min_mer, P.max_mer, P.slice_len); };
     // k_mer_check is a pure function of the segment: the backward chain reuses what the forward
     // chain decided (slot s cached in lane s)
-    u32 dc_k = 0, dc_have = 0;
+    u32 dc_k = 0, dc_have = 0, dc_saved = 0;  // dc_saved: k | items << 8 of the class table kept for the slot
     WT dc_sh = 0, dc_sl = 0;
     LaneMasks<NWB> mp;  // bounds of both halves of mate mp_pair
     int mp_pair = -1;
@@ -2019,6 +2030,8 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             d.kl = (int) (c >> 8);
             d.sh = readlane_word(dc_sh, slot);
             d.sl = readlane_word(dc_sl, slot);
+            d.ek = 0;
+            d.en = 0;
             return d;
         }
         const Segment sg = seg_of(slot);
@@ -2039,10 +2052,21 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             if (UB) lane_bounds<NWB>(r, sg.start, (int) sg.len, P.min_mer, P.max_mer, m);
             d = decide<NW, WT>(sv, P, (int) sg.len, sg.kmin, sg.kmax, ~0ull, m);
         }
+        // The classes of the last evaluated k are still in LDS.  When that k is the accepted one (the usual
+        // case: nothing after it passes its bound) keep them, so that flush() adds them without counting again.
+        u32 saved = 0;
+        if (d.ek > 0 && d.en <= kSaveItems && (d.ek == d.kh || d.ek == d.kl)) {
+            if (lane < d.en) {
+                sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane] = sm_canon<WT>(sm)[lane];
+                sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane] = sm_cnt(sm)[lane];
+            }
+            saved = (u32) d.ek | (d.en << 8);
+        }
         if ((int) lane == slot) {
             dc_k = (u32) d.kh | ((u32) d.kl << 8);
             dc_sh = d.sh;
             dc_sl = d.sl;
+            dc_saved = saved;
         }
         dc_have |= 1u << slot;
         return d;
@@ -2077,9 +2101,21 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             if (mp | mc) {
                 const Segment sg = seg_of(slot);
                 const ExactSmem sv = view_segment(sm, sg.mate, sg.start, sg.mate ? r1 : r0);
-                const KStat<WT> st = uni(eval_k<WT>(sv, (int) sg.len, k, 0.0));
-                if (mp) emit_k<WT>(sv, T, st.n_items, k, mp, false);
-                if (mc) emit_k<WT>(sv, T, st.n_items, k, mc, true);
+                const u32 sk = (u32) __builtin_amdgcn_readlane((int) dc_saved, slot);
+                u32 n_items;
+                if ((int) (sk & 255u) == k) {  // counted when the slot was decided
+                    n_items = sk >> 8;
+                    __syncthreads();
+                    if (lane < n_items) {
+                        sm_canon<WT>(sm)[lane] = sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane];
+                        sm_cnt(sm)[lane] = sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane];
+                    }
+                    __syncthreads();
+                } else {
+                    n_items = uni(eval_k<WT>(sv, (int) sg.len, k, 0.0)).n_items;
+                }
+                if (mp) emit_k<WT>(sv, T, n_items, k, mp, false);
+                if (mc) emit_k<WT>(sv, T, n_items, k, mc, true);
             }
         }
         if (clear) {
@@ -2164,7 +2200,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
     }
     if (4 * P.max_mer > n) {  // whole-read block, kmer.cpp:467-505
         PH_T0(t_wh);
-        Decision<WT> lt = {0, 0, 0, 0}, rt = {0, 0, 0, 0};
+        Decision<WT> lt = {0, 0, 0, 0, 0, 0}, rt = {0, 0, 0, 0, 0, 0};
         if (lef_k[0] == 0 || lef_k[1] == 0) {
             lt = seg_decide(4);
             if (lef_k[0] == 0) add_intent(4, lt.kh, 0, 0);
