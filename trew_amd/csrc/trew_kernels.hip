@@ -1696,6 +1696,44 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     return d;
 }
 
+// Keep / reuse the class table a decide() left in LDS (see Decision::ek): slot = where to keep it.
+// Returns k | items << 8 when kept, else 0.
+template <typename WT>
+__device__ __forceinline__ u32 save_classes(ExactSmem sm, const Decision<WT> &d, int slot) {
+    if (!(d.ek > 0 && d.en <= kSaveItems && (d.ek == d.kh || d.ek == d.kl))) return 0u;
+    if (lane_id() < d.en) {
+        sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane_id()] = sm_canon<WT>(sm)[lane_id()];
+        sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane_id()] = sm_cnt(sm)[lane_id()];
+    }
+    return (u32) d.ek | (d.en << 8);
+}
+// bring a kept table back into canon[] / cnt[] for emit_k; returns its number of items
+template <typename WT>
+__device__ __forceinline__ u32 restore_classes(ExactSmem sm, u32 saved, int slot) {
+    const u32 n_items = saved >> 8;
+    __syncthreads();
+    if (lane_id() < n_items) {
+        sm_canon<WT>(sm)[lane_id()] = sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane_id()];
+        sm_cnt(sm)[lane_id()] = sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane_id()];
+    }
+    __syncthreads();
+    return n_items;
+}
+
+// record the histogram of segment (already staged) at k into tables; `saved` (k | items << 8) names a
+// class table of this segment kept by save_classes in `slot`, used when it is the table of this k
+template <typename WT>
+__device__ void record_kept(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon, u32 saved, int slot) {
+    if (k <= 0 || table_mask == 0) return;
+    if ((int) (saved & 255u) == k) {
+        const u32 n_items = restore_classes<WT>(sm, saved, slot);
+        emit_k<WT>(sm, T, n_items, k, table_mask, strand_canon);
+        return;
+    }
+    const KStat<WT> st = uni(eval_k<WT>(sm, L, k, 0.0));
+    emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
+}
+
 // record the histogram of segment (already staged) at k into tables
 template <typename WT>
 __device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
@@ -1748,8 +1786,10 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
         const bool halves = UB && both;
         if (halves) mR = mL;  // the right half's bounds sit in lanes 32..63 of the same registers
         left = decide<NW, WT>(sm, P, (int) sL.len, sL.kmin, sL.kmax, ~0ull, mL, 0, halves ? 32 : 64);
+        const u32 keptL = save_classes<WT>(sm, left, 0);  // a junction read records this half as it was counted here
         sm = view_segment(sm, 0, sR.start, rd);
         right = decide<NW, WT>(sm, P, (int) sR.len, sR.kmin, sR.kmax, ~0ull, mR, halves ? 32 : 0, halves ? 32 : 64);
+        const u32 keptR = save_classes<WT>(sm, right, 1);
         const bool left_found = left.kh > 0 || left.kl > 0;
         const bool tgt_h = left_found && left.kh == right.kh && left.kh > 0;  // kmer.cpp:128
         const bool tgt_l = left_found && left.kl == right.kl && left.kl > 0;  // kmer.cpp:141
@@ -1760,10 +1800,10 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
             const bool rec_h = right.kh > 0 && (!left_found || (left.kh == 0));
             const bool rec_l = right.kl > 0 && (!left_found || (left.kl == 0));
             if (rec_h && rec_l && right.kh == right.kl) {
-                record<WT>(sm, T, (int) sR.len, right.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
+                record_kept<WT>(sm, T, (int) sR.len, right.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false, keptR, 1);
             } else {
-                if (rec_h) record<WT>(sm, T, (int) sR.len, right.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
-                if (rec_l) record<WT>(sm, T, (int) sR.len, right.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+                if (rec_h) record_kept<WT>(sm, T, (int) sR.len, right.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false, keptR, 1);
+                if (rec_l) record_kept<WT>(sm, T, (int) sR.len, right.kl, 1u << TREW_TABLE_BACKWARD_LOW, false, keptR, 1);
             }
         }
         if (left_found) {
@@ -1772,10 +1812,10 @@ __device__ void run_short(ExactSmem sm, const DevParams &P, const DevTable &T, c
             if (rec_h || rec_l) {
                 sm = view_segment(sm, 0, sL.start, rd);
                 if (rec_h && rec_l && left.kh == left.kl) {
-                    record<WT>(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false);
+                    record_kept<WT>(sm, T, (int) sL.len, left.kh, (1u << TREW_TABLE_FORWARD_HIGH) | (1u << TREW_TABLE_FORWARD_LOW), false, keptL, 0);
                 } else {
-                    if (rec_h) record<WT>(sm, T, (int) sL.len, left.kh, 1u << TREW_TABLE_FORWARD_HIGH, false);
-                    if (rec_l) record<WT>(sm, T, (int) sL.len, left.kl, 1u << TREW_TABLE_FORWARD_LOW, false);
+                    if (rec_h) record_kept<WT>(sm, T, (int) sL.len, left.kh, 1u << TREW_TABLE_FORWARD_HIGH, false, keptL, 0);
+                    if (rec_l) record_kept<WT>(sm, T, (int) sL.len, left.kl, 1u << TREW_TABLE_FORWARD_LOW, false, keptL, 0);
                 }
             }
             if (tgt_h || tgt_l) {
@@ -2054,14 +2094,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         }
         // The classes of the last evaluated k are still in LDS.  When that k is the accepted one (the usual
         // case: nothing after it passes its bound) keep them, so that flush() adds them without counting again.
-        u32 saved = 0;
-        if (d.ek > 0 && d.en <= kSaveItems && (d.ek == d.kh || d.ek == d.kl)) {
-            if (lane < d.en) {
-                sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane] = sm_canon<WT>(sm)[lane];
-                sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane] = sm_cnt(sm)[lane];
-            }
-            saved = (u32) d.ek | (d.en << 8);
-        }
+        const u32 saved = save_classes<WT>(sm, d, slot);
         if ((int) lane == slot) {
             dc_k = (u32) d.kh | ((u32) d.kl << 8);
             dc_sh = d.sh;
@@ -2104,13 +2137,7 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                 const u32 sk = (u32) __builtin_amdgcn_readlane((int) dc_saved, slot);
                 u32 n_items;
                 if ((int) (sk & 255u) == k) {  // counted when the slot was decided
-                    n_items = sk >> 8;
-                    __syncthreads();
-                    if (lane < n_items) {
-                        sm_canon<WT>(sm)[lane] = sm_save_canon<WT>(sm)[(u32) slot * kSaveItems + lane];
-                        sm_cnt(sm)[lane] = sm_save_cnt<WT>(sm)[(u32) slot * kSaveItems + lane];
-                    }
-                    __syncthreads();
+                    n_items = restore_classes<WT>(sm, sk, slot);
                 } else {
                     n_items = uni(eval_k<WT>(sv, (int) sg.len, k, 0.0)).n_items;
                 }
