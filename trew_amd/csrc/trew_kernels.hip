@@ -1734,6 +1734,18 @@ __device__ void record_kept(ExactSmem sm, const DevTable &T, int L, int k, u32 t
     emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
 }
 
+// the same right after the decide() of this very segment: its last class count is still in canon[] / cnt[]
+template <typename WT>
+__device__ void record_live(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon, const Decision<WT> &d) {
+    if (k <= 0 || table_mask == 0) return;
+    if (d.ek == k) {
+        emit_k<WT>(sm, T, d.en, k, table_mask, strand_canon);
+        return;
+    }
+    const KStat<WT> st = uni(eval_k<WT>(sm, L, k, 0.0));
+    emit_k<WT>(sm, T, st.n_items, k, table_mask, strand_canon);
+}
+
 // record the histogram of segment (already staged) at k into tables
 template <typename WT>
 __device__ void record(ExactSmem sm, const DevTable &T, int L, int k, u32 table_mask, bool strand_canon) {
@@ -1971,6 +1983,8 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
                 d.kh = (int) (c & 255u);
                 d.kl = (int) (c >> 8);
                 d.sh = d.sl = 0;
+                d.ek = 0;
+                d.en = 0;
                 if ((ti <= last_rec[0] && d.kh > 0) || (ti <= last_rec[1] && d.kl > 0)) {  // record() wants the slice staged
                     u32 st, sl;
                     long_slice(ti, mid, bonus, SL, st, sl);
@@ -1997,10 +2011,14 @@ __device__ void run_long(ExactSmem sm, const DevParams &P, const DevBatch &B, co
             const Decision<WT> d = slice_decide(tj, tj == snum ? ~0ull : (tj == 1 ? ~0ull : allk), -1);
             const bool rh = !rend[0] && d.kh > 0, rl = !rend[1] && d.kl > 0;
             if (rh && rl && d.kh == d.kl) {
-                record<WT>(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false);
-            } else {
-                if (rh) record<WT>(sm, T, slice_len(tj), d.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false);
-                if (rl) record<WT>(sm, T, slice_len(tj), d.kl, 1u << TREW_TABLE_BACKWARD_LOW, false);
+                record_live<WT>(sm, T, slice_len(tj), d.kh, (1u << TREW_TABLE_BACKWARD_HIGH) | (1u << TREW_TABLE_BACKWARD_LOW), false, d);
+            } else {  // two different k: the first record may count again and overwrite the live table
+                Decision<WT> d2 = d;
+                if (rh) {
+                    record_live<WT>(sm, T, slice_len(tj), d.kh, 1u << TREW_TABLE_BACKWARD_HIGH, false, d2);
+                    if (d2.ek != d.kh) d2.ek = 0;
+                }
+                if (rl) record_live<WT>(sm, T, slice_len(tj), d.kl, 1u << TREW_TABLE_BACKWARD_LOW, false, d2);
             }
             const int tk[2] = {d.kh, d.kl};
 #pragma unroll
