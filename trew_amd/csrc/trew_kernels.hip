@@ -1464,6 +1464,7 @@ struct LaneMasks {
     u32 V[NW];  // bit i: window i has no N and fits the segment
     u32 E[NW];  // bit i: base i == base i+k (meaningful where windows i and i+1 are both valid)
     double ub;  // maxbucket / COUNT, an upper bound of MAX / COUNT (0 where COUNT == 0)
+    u32 runs;   // number of runs of adjacent same-class windows (Lemma A): what counting the classes of this k costs
 };
 
 template <int NW>
@@ -1572,6 +1573,15 @@ __device__ __forceinline__ void lane_bounds_at(const ReadRef &rd, u32 s, int L, 
     const u32 m8 = max(max(max(c000, c001), max(c010, c011)), max(max(c100, c101), max(c110, c111)));
     // k = 64 is not bounded here (shift amounts stay below 64): never prune it
     out.ub = (k > gmax || k >= 64 || count == 0) ? ((k >= 64 && k <= gmax) ? 2.0 : 0.0) : (double) m8 / (double) count;
+    {
+        u32 links = 0;  // valid windows i, i+1 that share a class
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const u32 vn = j + 1 < NW ? out.V[j + 1 < NW ? j + 1 : 0] : 0u;
+            links += __popc(out.V[j] & out.E[j] & alignbit(vn, out.V[j], 1u));
+        }
+        out.runs = count - links;
+    }
     PH_ADD(PH_BOUNDS, t_ph);
 }
 
@@ -1614,11 +1624,27 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
     // never accepted and never moves the running frequency (kmer.cpp:2225-2236).
     u64 closed_low = 0, closed_high = 0;
     u64 todo = cand & all_k_mask(kmin, kmax);
+    // Speculative skip (HAVE_UB only).  Counting the classes of a k with many runs is the expensive
+    // case, and it is usually a k that cannot matter: a TTAGGG read probed at k = 5 (bound 0.5, ~45 runs)
+    // just before k = 6 is accepted at 0.9.  Such a k is passed over; that is exact provided every k
+    // accepted later in a selection loop the skipped k was eligible for has a frequency >= the bound of
+    // the skipped k and is not a multiple of it (then the skipped k could only have raised the threshold
+    // to a value the later k clears and closed multiples nobody took), and at least one such k exists
+    // (else the skipped k might be the answer).  If the check fails the segment is decided again with
+    // every k counted.
+    constexpr u32 kHeavyRuns = 24;
+    bool strict = !HAVE_UB;
+    int sk_k[2] = {0, 0};
+    double sk_ub[2] = {0.0, 0.0};
+    u32 sk_el[2] = {0, 0}, sk_ok[2] = {0, 0};
+    bool viol = false;
+    const u64 todo0 = todo;
     // lane l <-> k = MIN_MER + l (as in lane_bounds); only used when HAVE_UB
     // lanes [lane_base, lane_base + lane_span) hold this segment's bounds (lane_bounds_pair: half a wave)
     const int kl = P.min_mer + (int) lane_id() - lane_base;
     const u32 klb = (u32) (kl - 1) & 63u;
     const bool my_lane = (int) lane_id() >= lane_base && (int) lane_id() < lane_base + lane_span;
+again:
     for (;;) {
         const double thr_lo = P.low > tf_low ? P.low : tf_low;     // MAX(LOW_BASELINE, target_frequency_low)
         const double thr_hi = P.high > tf_high ? P.high : tf_high; // MAX(HIGH_BASELINE, target_frequency_high)
@@ -1641,6 +1667,18 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
         if (!lo_open && !hi_open) continue;
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
         KStat<WT> st;
+        if (HAVE_UB && !strict) {
+            const int src = k - P.min_mer + lane_base;
+            if ((u32) __builtin_amdgcn_readlane((int) M.runs, src) > kHeavyRuns && (sk_k[0] == 0 || sk_k[1] == 0)) {
+                const double ub = readlane_f64(M.ub, src);
+                const u32 el = ((lo_open && ub >= thr_lo) ? 1u : 0u) | ((hi_open && ub >= thr_hi) ? 2u : 0u);
+                const int s = sk_k[0] == 0 ? 0 : 1;
+                sk_k[s] = k;
+                sk_ub[s] = ub;
+                sk_el[s] = el;
+                continue;
+            }
+        }
         if (HAVE_UB) {
             const int src = k - P.min_mer + lane_base;
             // the window masks of this k were computed bit-parallel by lane `src`: fetch them
@@ -1679,17 +1717,44 @@ __device__ Decision<WT> decide(ExactSmem sm, const DevParams &P, int L, int kmin
         if (st.pruned || st.count == 0) continue;  // 0/0 = NaN fails every >=
         const double f = (double) st.maxc / (double) st.count;
         if (is_homopolymer<WT>(st.maxseq, k)) continue;
+        u32 acc = 0;
         if (lo_open && f >= thr_lo) {
             d.kl = k;
             tf_low = f;
             closed_low |= multiples_mask(k);
             d.sl = st.maxseq;
+            acc |= 1u;
         }
         if (hi_open && f >= thr_hi) {
             d.kh = k;
             tf_high = f;
             closed_high |= multiples_mask(k);
             d.sh = st.maxseq;
+            acc |= 2u;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (sk_k[s] && (acc & sk_el[s])) {
+                if (f < sk_ub[s] || k % sk_k[s] == 0) viol = true;
+                sk_ok[s] |= acc & sk_el[s];
+            }
+        }
+    }
+    if (HAVE_UB && !strict) {
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            if (sk_k[s] && (sk_el[s] & ~sk_ok[s])) viol = true;
+        if (viol) {  // decide again, counting every k
+            strict = true;
+            d.kh = d.kl = 0;
+            d.sh = d.sl = 0;
+            d.ek = 0;
+            d.en = 0;
+            tf_low = tf_high = 0.0;
+            closed_low = closed_high = 0;
+            todo = todo0;
+            sk_k[0] = sk_k[1] = 0;
+            goto again;
         }
     }
     PH_ADD(PH_DECIDE, t_ph);
