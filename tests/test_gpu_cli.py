@@ -150,3 +150,45 @@ def test_cli_bgzf_input(tmp_path):
     assert run("short", "5", "32", z1, "-t", "4") == want_single
     want_pair = expected([(z1, O.run_pair(O.OracleParams(), r1, r2))], 5)
     assert run("short", "5", "32", "--paired_end", "--fq1", z1, "--fq2", z2, "-t", "4") == want_pair
+
+
+def _rank_scan(rank, world, port, n, q):
+    import torch.distributed as dist
+
+    import trew_amd as T
+    from trew_amd.dist import allreduce_rows_into_table, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n, rank, world)
+    buf, st, nd = capi.synth_short_ascii(20250218, lo, hi - lo, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=hi - lo + 8, max_batch_words=1 << 22) as t:
+        t.submit_reads(reads)
+        t.wait()
+        merged = allreduce_rows_into_table(t, t.collect_rows())
+    q.put((rank, capi.rows_to_tables(merged)))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reduce_through_the_device_table():
+    """The reduction bench.py uses for N > 1 (all_gather of rows, add_rows into the device table, collect),
+    with two processes sharing this GPU over gloo: every rank must end with the tables of all reads."""
+    import torch.multiprocessing as mp
+
+    n, world = 40000, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 200)
+    procs = [ctx.Process(target=_rank_scan, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, n, 150)
+    want = O.run_short(O.OracleParams(), [buf[s:e + 1] for s, e in zip(st, nd)])
+    for rank, got in res:
+        assert got == want, rank
