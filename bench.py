@@ -4,13 +4,21 @@
 Contract (see the task prompt): `python bench.py --gpus N --steps K --warmup W`;
 for N > 1 it is launched by torch.distributed.run, one rank per GPU.  A "step"
 is one pass of the hot path (prefilter kernel + exact kernel + count-table
-accumulation) over one batch of `--reads` synthetic reads that are already
-resident in HBM when the timed region starts.  Reads are sharded contiguously
-across ranks (weak scaling: every rank scans its own --reads reads); the only
-exchange is the final reduction of the count tables, which is inside the timed
-region.  Rank 0 prints ONE JSON line.
+accumulation) over one batch of synthetic reads that are already resident in HBM
+when the timed region starts.  The K passes alternate between two batch slots
+(two HIP streams), so the prefilter of pass i+1 runs beside the exact kernel of
+pass i -- the same double buffering the `trew` host uses.  Reads are sharded
+contiguously across ranks (weak scaling: every rank scans its own reads); the
+only exchange is the final reduction of the count tables, inside the timed region.
+Rank 0 prints ONE JSON line.
+
+N = 1 (default): the BASELINE metric on config 2 (10 M x 150 bp).  The same run then
+times config 3 (50 M pairs of 2 x 150 bp) and config 4 (1 M ONT-like reads) and
+attaches them as `other_configs`, each with its own oracle check.
+N > 1: every rank scans config 5's per-GPU share (1 B reads / 8 = 125 M reads).
 """
 import argparse
+import csv
 import json
 import os
 import sys
@@ -22,9 +30,13 @@ if ROOT not in sys.path:
 
 SEED = 20250218
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9
 # integer-issue peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (one VALU lane-op per lane per clock)
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
 EVALS_PER_150BP_READ = 3220  # (window,k) evaluations per 150-bp read at 5 32
+CONFIG5_READS_PER_GPU = 1_000_000_000 // 8  # BASELINE config 5: 1 B reads over 8 GPUs
+PROFILE_ROUNDS = ("r02", "r01")  # newest committed rocprofv3 summaries first
 
 
 def usable_cores():
@@ -50,20 +62,186 @@ def usable_cores():
     return n
 
 
+def committed_profile(n, L):
+    """HBM traffic and VALU issue figures of both kernels from the committed rocprofv3 PMC run of this same
+    command (profiles/<round>/pmc_summary_final.csv + kernel_stats_final.csv, written by profiles/summarize.py).
+    Returns (traffic_by_kernel, valu_by_kernel, round) or (None, None, None) when the configuration differs."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj["config"] != {"reads_per_gpu": n, "read_len": L}:
+            return None, None, None
+    except (OSError, KeyError, ValueError):
+        return None, None, None
+    traffic = {k: round(v["hbm_bytes_per_launch"]) for k, v in tj["kernels"].items()}
+    rnd = os.path.basename(os.path.dirname(tj.get("source", "profiles/r01/x")))
+    prof = os.path.join(ROOT, "profiles", rnd)
+    valu = {}
+    try:
+        cnt, dur = {}, {}
+        for r in csv.DictReader(open(os.path.join(prof, "pmc_summary_final.csv"))):
+            for kern in ("filter_kernel", "exact_kernel"):
+                if kern in r["kernel"]:
+                    cnt.setdefault(kern, {})[r["counter"]] = float(r["avg_per_dispatch"])
+        for r in csv.DictReader(open(os.path.join(prof, "kernel_stats_final.csv"))):
+            for kern in ("filter_kernel", "exact_kernel"):
+                if kern in r["Name"]:
+                    dur[kern] = float(r["AverageNs"])
+        rates = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
+        for kern in cnt:
+            c = cnt[kern]
+            if "SQ_ACTIVE_INST_VALU" not in c or kern not in dur:
+                continue
+            simd_cycles = N_SIMD * dur[kern] * 1e-9 * CLOCK_HZ
+            active = c["SQ_ACTIVE_INST_VALU"] * 4.0  # rocprof's VALUBusy definition
+            valu[kern] = {
+                "insts_valu": round(c.get("SQ_INSTS_VALU", 0)),
+                "insts_salu": round(c.get("SQ_INSTS_SALU", 0)),
+                "profiled_launch_ms": round(dur[kern] * 1e-6, 4),
+                "issue_frac": round(active / simd_cycles, 3),
+                "cycles_per_valu_inst": round(active / c["SQ_INSTS_VALU"], 2) if c.get("SQ_INSTS_VALU") else None,
+            }
+        valu["cycles_per_inst_by_class"] = rates["cycles_per_wave_inst"]
+        valu["source"] = "profiles/%s/pmc_summary_final.csv, kernel_stats_final.csv; profiles/valu_rate.json (tools/valu_rate.hip on the box)" % rnd
+    except (OSError, KeyError, ValueError):
+        valu = {}
+    return traffic, (valu or None), rnd
+
+
+class Workload:
+    """One BASELINE configuration resident in HBM: context, device batch, bookkeeping."""
+
+    def __init__(self, T, capi, mode, n, L, args, dev_index, first_read):
+        self.T, self.capi, self.mode, self.n, self.L = T, capi, mode, n, L
+        dev_mode = {"short": T.MODE_SHORT, "pair": T.MODE_PAIR, "long": T.MODE_LONG}[mode]
+        self.n_reads_dev = 2 * n if mode == "pair" else n  # n counts pairs in pair mode
+        self.t = t = T.TrewHip(mode=dev_mode, min_mer=args.min_mer, max_mer=args.max_mer, device=dev_index, n_slots=max(1, args.streams),
+                               max_batch_words=16, max_batch_reads=self.n_reads_dev, table_log2_slots=20, flags=args.flags)
+        stride = 3 * ((L + 31) // 32)
+        self.to_free = []
+        if mode == "short":
+            self.d_words = t.malloc(n * stride * 4 + 64)
+            t.synth_short_device(SEED, first_read, n, L, self.d_words)
+            self.batch = t.device_uniform_batch(self.d_words, n, L)
+            self.bases_per_step = n * L
+            self.to_free = [self.d_words]
+        elif mode == "pair":
+            self.d_words = t.malloc(2 * n * stride * 4 + 64)
+            t.synth_pair_device(SEED, first_read, n, L, self.d_words)
+            self.batch = t.device_uniform_batch(self.d_words, 2 * n, L)
+            self.bases_per_step = 2 * n * L
+            self.to_free = [self.d_words]
+        else:
+            self.batch, self.to_free, self.bases_per_step = t.synth_long_device(SEED, first_read, n)
+            self.d_words = self.to_free[0]
+
+    def close(self):
+        for ptr in self.to_free:
+            self.t.free(ptr)
+        self.t.close()
+
+    def sub_batch(self, m):
+        """The first m units of the resident batch."""
+        if self.mode == "short":
+            return self.t.device_uniform_batch(self.d_words, m, self.L)
+        if self.mode == "pair":
+            return self.t.device_uniform_batch(self.d_words, 2 * m, self.L)
+        b = self.batch
+        return self.capi.Batch(b.words, b.n_words, b.offsets, b.lengths, 0, 0, m, 1, b.max_length)
+
+
+def timed_run(w, args, steps, warmup, world, barrier, reduce_fn):
+    """W warm-up passes, then exactly `steps` passes between barriers.  Returns a dict of measurements."""
+    t, nslots = w.t, max(1, args.streams)
+    for i in range(warmup):
+        t.submit(w.batch, i % nslots)
+    for s in range(nslots):
+        t.wait(s)
+    serial = None
+    if warmup:
+        for s in range(nslots):
+            try:
+                t.last_timing(s, want_flagged=False)  # drop the warm-up launches from the averages
+            except w.T.TrewHipError:
+                pass
+        t.collect_rows()  # first collect allocates its device scratch: part of warm-up, not of the timed job
+    # per-kernel durations with the device to themselves: two passes on ONE stream (not part of the timed region)
+    t.submit(w.batch, 0)
+    t.submit(w.batch, 0)
+    t.wait(0)
+    serial = t.last_timing(0, want_flagged=False)[:2]
+    t.reset_tables()
+    barrier()
+    t0 = time.perf_counter()
+    # the K passes are queued on the slots' HIP streams round-robin (each slot serialises its own passes, the
+    # slots overlap each other; launch latency hides behind the running kernels) and waited for once
+    for i in range(steps):
+        t.submit(w.batch, i % nslots)
+    for s in range(nslots):
+        t.wait(s)
+    host_ms = (time.perf_counter() - t0) * 1e3 / steps
+    rows = t.collect_rows() if world == 1 else None
+    merged = reduce_fn(t, rows)
+    barrier()
+    dt = time.perf_counter() - t0
+    # mean HIP-event durations of the timed passes, on the kernels' own streams
+    fs, es, cnt, nflag = 0.0, 0.0, 0, 0
+    for s in range(min(nslots, steps)):
+        k = len(range(s, steps, nslots))
+        a, b, nf = t.last_timing(s)
+        fs, es, cnt, nflag = fs + a * k, es + b * k, cnt + k, nf
+    return {"dt": dt, "host_ms": host_ms, "filter_ms": fs / cnt, "exact_ms": es / cnt, "serial_ms": serial, "nflag": int(nflag), "rows": merged}
+
+
+def oracle_check(w, args, O, cores):
+    """GPU tables vs the CPU oracle on a bounded prefix of the workload; returns (ok, sample text, bases, seconds, threads)."""
+    t, capi = w.t, w.capi
+    op = O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer)
+    t.reset_tables()
+    if w.mode == "short":
+        m = min(max(args.cpu_reads, cores * 250_000), w.n)  # ~10-30 s of CPU work: 250 k reads per usable core
+        buf, st, nd = capi.synth_short_ascii(SEED, 0, m, w.L)
+        want, cpu_dt = O.run_short_mt_timed(op, buf, st, nd, cores)
+        bases, used, what = m * w.L, cores, "first %d reads" % m
+    elif w.mode == "pair":
+        m = min(args.cpu_pairs, w.n)
+        b1, b2, st, nd = capi.synth_pair_ascii(SEED, 0, m, w.L)
+        c0 = time.perf_counter()
+        want = O.run_pair(op, [b1[s:e + 1] for s, e in zip(st, nd)], [b2[s:e + 1] for s, e in zip(st, nd)])
+        cpu_dt = time.perf_counter() - c0
+        bases, used, what = 2 * m * w.L, 1, "first %d pairs" % m
+    else:
+        m = min(args.cpu_long_reads, w.n)
+        buf, st, nd = capi.synth_long_ascii(SEED, 0, m)
+        c0 = time.perf_counter()
+        want = O.run_long(op, [buf[s:e + 1] for s, e in zip(st, nd)])
+        cpu_dt = time.perf_counter() - c0
+        bases, used, what = int((nd - st + 1).sum()), 1, "first %d reads" % m
+    t.submit(w.sub_batch(m), 0)
+    t.wait(0)
+    got = t.collect()
+    return got == want, what, bases, cpu_dt, used
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (config 2: 10M x 150 bp)")
+    ap.add_argument("--reads", type=int, default=0, help="reads (pairs) per GPU per step; 0 = the BASELINE size of the mode: "
+                    "short 10 M at N = 1 (config 2) and 125 M at N > 1 (config 5's share), pair 50 M (config 3), long 1 M (config 4)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--min-mer", type=int, default=5)
     ap.add_argument("--max-mer", type=int, default=32)
     ap.add_argument("--cpu-reads", type=int, default=1_000_000, help="reads of the same workload timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-pairs", type=int, default=30_000, help="pairs of config 3 checked against the oracle")
+    ap.add_argument("--cpu-long-reads", type=int, default=5_000, help="reads of config 4 checked against the oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, --mode short only: do not time configs 3 and 4")
+    ap.add_argument("--other-steps", type=int, default=0, help="passes per other config (default: min(steps, 10))")
+    ap.add_argument("--streams", type=int, default=2, help="batch slots (HIP streams) the passes alternate between")
     ap.add_argument("--flags", type=int, default=0, help="TREW_FLAG_* (debug experiments only)")
     ap.add_argument("--mode", default="short", choices=["short", "pair", "long"],
-                    help="short = the BASELINE metric (config 2); pair / long = configs 3 / 4, reported for information")
+                    help="short = the BASELINE metric (config 2); pair / long = configs 3 / 4 as the primary line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     args = ap.parse_args()
 
@@ -72,13 +250,19 @@ def main():
 
     import trew_amd as T
     from trew_amd import capi
-    from trew_amd.dist import allreduce_rows_into_table
+    from trew_amd.dist import allreduce_rows_into_table, allreduce_table_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_dev = max(1, torch.cuda.device_count())
-    dev_index = local_rank % n_dev if world > 1 else 0  # one GPU per rank; wraps only in a one-GPU rehearsal
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        sys.exit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and args.backend == "nccl" and local_world > n_dev:
+        sys.exit("bench.py: %d ranks on this node but %d GPU(s) visible -- RCCL needs one GPU per rank "
+                 "(use --backend gloo to rehearse several ranks on one GPU)" % (local_world, n_dev))
+    dev_index = local_rank % n_dev if world > 1 else 0  # one GPU per rank; wraps only in a one-GPU gloo rehearsal
     torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -87,113 +271,60 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     dev = torch.device("cuda", dev_index)
-    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")
-    if args.gpus != world:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
-    n, L = args.reads, args.read_len
-    stride = 3 * ((L + 31) // 32)
-    first_read = rank * n  # contiguous read-index ranges per rank
-    dev_mode = {"short": T.MODE_SHORT, "pair": T.MODE_PAIR, "long": T.MODE_LONG}[args.mode]
-    n_reads_dev = 2 * n if args.mode == "pair" else n  # --reads counts pairs in pair mode
-    t = T.TrewHip(mode=dev_mode, min_mer=args.min_mer, max_mer=args.max_mer, device=dev.index, n_slots=1,
-                  max_batch_words=16, max_batch_reads=n_reads_dev, table_log2_slots=20, flags=args.flags)
-    to_free = []
-    if args.mode == "short":
-        d_words = t.malloc(n * stride * 4 + 64)
-        t.synth_short_device(SEED, first_read, n, L, d_words)
-        batch = t.device_uniform_batch(d_words, n, L)
-        bases_per_step = n * L
-    elif args.mode == "pair":
-        d_words = t.malloc(2 * n * stride * 4 + 64)
-        t.synth_pair_device(SEED, first_read, n, L, d_words)
-        batch = t.device_uniform_batch(d_words, 2 * n, L)
-        bases_per_step = 2 * n * L
-    else:
-        batch, to_free, bases_per_step = t.synth_long_device(SEED, first_read, n)
-        d_words = to_free[0]
+    L = args.read_len
+    default_reads = {"short": 10_000_000 if world == 1 else CONFIG5_READS_PER_GPU, "pair": 50_000_000, "long": 1_000_000}
+    n = args.reads or default_reads[args.mode]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        t.submit(batch, 0)
-        t.wait(0)
+    def reduce_fn(t, rows):
+        if world == 1:
+            return rows
+        if args.backend == "nccl":
+            return allreduce_table_device(t, dev)  # compaction -> RCCL all_gather -> add into the device table, all in HBM
+        return allreduce_rows_into_table(t, t.collect_rows(), device=torch.device("cpu"))
 
-    for _ in range(args.warmup):
-        step()
-    if args.warmup:
-        t.last_timing(0, want_flagged=False)  # drop the warm-up launches from the averages
-        t.collect_rows()  # first collect allocates its device scratch: part of warm-up, not of the timed job
-    t.reset_tables()
-    filt_ms, exact_ms = [], []
-    barrier()
-    t0 = time.perf_counter()
-    host_ms = []
-    # the K passes are queued back to back on the slot's HIP stream (they serialise on the device,
-    # launch latency hides behind the running kernels) and waited for once
-    h0 = time.perf_counter()
-    for _ in range(args.steps):
-        t.submit(batch, 0)
-    t.wait(0)
-    host_ms.append((time.perf_counter() - h0) * 1e3 / args.steps)
-    a, b, nflag = t.last_timing(0)  # mean over the K submits, HIP events on the kernels' own stream
-    filt_ms.append(a)
-    exact_ms.append(b)
-    rows = t.collect_rows()
-    merged = allreduce_rows_into_table(t, rows, device=comm_dev)
-    barrier()
-    dt = time.perf_counter() - t0
+    w = Workload(T, capi, args.mode, n, L, args, dev.index, rank * n)  # contiguous read-index ranges per rank
+    m = timed_run(w, args, args.steps, args.warmup, world, barrier, reduce_fn)
+    dt = m["dt"]
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else torch.device("cpu"))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    bases = float(world) * bases_per_step * args.steps
+    bases = float(world) * w.bases_per_step * args.steps
     value = bases / dt / 1e9
     ms_per_step = dt / args.steps * 1e3
 
+    def workload_name(mode, cnt, bases_per_step):
+        return {"short": "short %d %d, %d synthetic %d bp reads per GPU (TTAGGG-seeded, seed %d)" % (args.min_mer, args.max_mer, cnt, L, SEED),
+                "pair": "short %d %d --paired_end, %d synthetic 2x%d bp pairs per GPU (seed %d)" % (args.min_mer, args.max_mer, cnt, L, SEED),
+                "long": "long %d %d, %d synthetic ONT-like reads per GPU (N50 ~20 kb, %.2f Gbases, seed %d)" % (args.min_mer, args.max_mer, cnt, bases_per_step / 1e9, SEED)}[mode]
+
     out = None
     if rank == 0:
-        f_avg = sum(filt_ms) / len(filt_ms)
-        e_avg = sum(exact_ms) / len(exact_ms)
+        f_avg, e_avg = m["filter_ms"], m["exact_ms"]
         dom, dom_ms = ("filter_kernel", f_avg) if f_avg >= e_avg else ("exact_kernel", e_avg)
         # algorithmic bytes per launch: 0.25 B per base (2-bit input) + 8 B per read (offset/length), SURVEY 8(d).
         # Long mode counts every base of a read although only the outer slices are touched.
-        alg_bytes = bases_per_step * 0.25 + n_reads_dev * 8.0
+        alg_bytes = w.bases_per_step * 0.25 + w.n_reads_dev * 8.0
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         evals = EVALS_PER_150BP_READ * (L / 150.0) * n if args.mode != "long" else 7420.0 * n
-        # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
-        # (profiles/traffic.json, written by profiles/summarize.py); null when the configuration differs
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.mode == "short" and tj["config"] == {"reads_per_gpu": n, "read_len": L} and args.min_mer == 5 and args.max_mer == 32:
-                traffic = round(tj["kernels"][dom]["hbm_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            traffic = None
-        # VALU occupancy of the dominant kernel from the committed rocprofv3 run of this same command
-        # (profiles/r01/pmc_summary_final.csv + kernel_stats_final.csv): rocprof's VALUBusy definition,
-        # SQ_ACTIVE_INST_VALU * 4 / (SIMDs * kernel cycles), with the profiled average duration
-        valu_busy = None
-        try:
-            if traffic is not None:
-                import csv
-                prof = os.path.join(ROOT, "profiles", "r01")
-                active = dur_ns = None
-                for r in csv.DictReader(open(os.path.join(prof, "pmc_summary_final.csv"))):
-                    if dom in r["kernel"] and r["counter"] == "SQ_ACTIVE_INST_VALU":
-                        active = float(r["avg_per_dispatch"])
-                for r in csv.DictReader(open(os.path.join(prof, "kernel_stats_final.csv"))):
-                    if dom in r["Name"]:
-                        dur_ns = float(r["AverageNs"])
-                if active and dur_ns:
-                    valu_busy = round(active * 4.0 / (256 * 4 * dur_ns * 1e-9 * 2.4e9), 3)
-        except (OSError, KeyError, ValueError):
-            valu_busy = None
+        traffic_all, valu, prof_round = (None, None, None)
+        if args.mode == "short" and args.min_mer == 5 and args.max_mer == 32:
+            traffic_all, valu, prof_round = committed_profile(n, L)
+        traffic = traffic_all.get(dom) if traffic_all else None
+        s_f, s_e = m["serial_ms"]
+        s_dom = s_f if dom == "filter_kernel" else s_e
+        workload = workload_name(args.mode, n, w.bases_per_step)
+        if world > 1 and args.mode == "short" and n == CONFIG5_READS_PER_GPU:
+            workload += "; config 5's per-GPU share (1 B reads / 8)"
         out = {
             "metric": {"short": "Gbases/s scanned (short %d %d, %d bp reads)" % (args.min_mer, args.max_mer, L),
                        "pair": "Gbases/s scanned (short %d %d --paired_end, 2x%d bp)" % (args.min_mer, args.max_mer, L),
@@ -210,12 +341,12 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": {"short": "short %d %d, %d synthetic %d bp reads per GPU (TTAGGG-seeded, seed %d)" % (args.min_mer, args.max_mer, n, L, SEED),
-                             "pair": "short %d %d --paired_end, %d synthetic 2x%d bp pairs per GPU (seed %d)" % (args.min_mer, args.max_mer, n, L, SEED),
-                             "long": "long %d %d, %d synthetic ONT-like reads per GPU (N50 ~20 kb, %.2f Gbases, seed %d)" % (args.min_mer, args.max_mer, n, bases_per_step / 1e9, SEED)}[args.mode],
+                "workload": workload,
                 "reads_per_gpu": n,
                 "read_len": L,
-                "parallelism": "dp%d read-sharded, one table all-reduce" % world,
+                "streams": max(1, args.streams),
+                "parallelism": "dp%d read-sharded, tables reduced once at the end%s" % (
+                    world, "" if world == 1 else (" (RCCL all_gather of compacted rows, merged by the device table)" if args.backend == "nccl" else " (gloo rehearsal)")),
             },
             "roofline": {
                 "bound": "hbm",
@@ -226,51 +357,32 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
-                "valu_busy": valu_busy,
-                "note": "integer-issue bound, not HBM bound (SURVEY 8(d)): valu_busy = share of SIMD cycles issuing VALU work in the committed rocprofv3 PMC run (profiles/r01); %.3g (window,k) evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
-                        % (evals / ((f_avg + e_avg) * 1e-3), evals / ((f_avg + e_avg) * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
+                "serial_launch_ms": {"filter_kernel": round(s_f, 4), "exact_kernel": round(s_e, 4)},
+                "frac_serial": round(alg_bytes / (s_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "valu": valu,
+                "valu_busy": (valu or {}).get(dom, {}).get("issue_frac"),
+                "note": "integer-issue bound, not HBM bound (SURVEY 8(d)). avg_launch_ms: HIP events over the timed region, where the %d slots overlap "
+                        "(a kernel shares the SIMDs with the other slot's kernel, so its own launch is longer than alone); serial_launch_ms: the same "
+                        "kernels alone on one stream, measured in this run outside the timed region.  valu: SQ counters of the committed rocprofv3 PMC "
+                        "run of this command (profiles/%s), issue_frac = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs x kernel cycles at 2.4 GHz).  %.3g (window,k) "
+                        "evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
+                        % (max(1, args.streams), prof_round or "none for this configuration", evals / (ms_per_step * 1e-3),
+                           evals / (ms_per_step * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
             },
-            "flagged_reads_per_step": int(nflag),
-            "host_ms_per_step": round(sum(host_ms) / len(host_ms), 4),
-            "table_rows": int(len(merged)),
+            "flagged_reads_per_step": m["nflag"],
+            "reads_per_s": round(world * n * args.steps / dt, 1),
+            "host_ms_per_step": round(m["host_ms"], 4),
+            "table_rows": int(len(m["rows"])),
         }
 
     # CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_cpu:
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu
+    O = None
+    if do_cpu:
         import oracle as O
 
         cores = usable_cores()
-        op = O.OracleParams(min_mer=args.min_mer, max_mer=args.max_mer)
-        t.reset_tables()
-        if args.mode == "short":
-            # bounded sample, ~10-30 s of CPU work: 250 k reads per usable core
-            m = min(max(args.cpu_reads, cores * 250_000), n)
-            buf, st, nd = capi.synth_short_ascii(SEED, 0, m, L)
-            want, cpu_dt = O.run_short_mt_timed(op, buf, st, nd, cores)
-            t.submit(t.device_uniform_batch(d_words, m, L), 0)
-            sample_bases, used = m * L, cores
-            what = "first %d reads" % m
-        elif args.mode == "pair":
-            m = min(args.cpu_reads // 10, n)
-            b1, b2, st, nd = capi.synth_pair_ascii(SEED, 0, m, L)
-            c0 = time.perf_counter()
-            want = O.run_pair(op, [b1[s:e + 1] for s, e in zip(st, nd)], [b2[s:e + 1] for s, e in zip(st, nd)])
-            cpu_dt = time.perf_counter() - c0
-            t.submit(t.device_uniform_batch(d_words, 2 * m, L), 0)
-            sample_bases, used = 2 * m * L, 1
-            what = "first %d pairs" % m
-        else:
-            m = min(args.cpu_reads // 100, n)
-            buf, st, nd = capi.synth_long_ascii(SEED, 0, m)
-            c0 = time.perf_counter()
-            want = O.run_long(op, [buf[s:e + 1] for s, e in zip(st, nd)])
-            cpu_dt = time.perf_counter() - c0
-            sub = capi.Batch(batch.words, batch.n_words, batch.offsets, batch.lengths, 0, 0, m, 1, batch.max_length)
-            t.submit(sub, 0)
-            sample_bases, used = int((nd - st + 1).sum()), 1
-            what = "first %d reads" % m
-        t.wait(0)
-        got = t.collect()
+        ok, what, sample_bases, cpu_dt, used = oracle_check(w, args, O, cores)
         out["cpu_baseline"] = {
             "value": round(sample_bases / cpu_dt / 1e9, 6),
             "unit": "Gbases/s",
@@ -279,15 +391,46 @@ def main():
             "sample": "%s of the same synthetic workload (%.1f Mbases), oracle/trew_oracle.c with %d thread(s), %.1f s" % (
                 what, sample_bases / 1e6, used, cpu_dt),
         }
-        out["parity"] = bool(got == want)
-        out["parity_note"] = "GPU tables vs CPU oracle on the sample: %s" % ("bit-exact" if got == want else "MISMATCH")
+        out["parity"] = bool(ok)
+        out["parity_note"] = "GPU tables vs CPU oracle on the sample: %s" % ("bit-exact" if ok else "MISMATCH")
+    w.close()
+
+    # configs 3 and 4 at BASELINE size in the same run (N = 1, default invocation), each checked against the oracle
+    if rank == 0 and world == 1 and args.mode == "short" and not args.no_other_configs:
+        others = []
+        osteps = args.other_steps or max(1, min(args.steps, 10))
+        for mode in ("pair", "long"):
+            cnt = default_reads[mode]
+            ow = Workload(T, capi, mode, cnt, L, args, dev.index, 0)
+            om = timed_run(ow, args, osteps, min(args.warmup, 2), 1, barrier, reduce_fn)
+            entry = {
+                "workload": workload_name(mode, cnt, ow.bases_per_step),
+                "value": round(ow.bases_per_step * osteps / om["dt"] / 1e9, 3),
+                "unit": "Gbases/s",
+                "steps": osteps,
+                "ms_per_step": round(om["dt"] / osteps * 1e3, 4),
+                "reads_per_s": round(cnt * osteps / om["dt"], 1),
+                "avg_launch_ms": {"filter_kernel": round(om["filter_ms"], 4), "exact_kernel": round(om["exact_ms"], 4)},
+                "serial_launch_ms": {"filter_kernel": round(om["serial_ms"][0], 4), "exact_kernel": round(om["serial_ms"][1], 4)},
+                "flagged_per_step": om["nflag"],
+                "table_rows": int(len(om["rows"])),
+            }
+            if mode == "long":
+                entry["note"] = "every base of a read is counted although only the chained outer slices are loaded (SURVEY 8(d)): reads_per_s is the size-independent figure"
+            if do_cpu:
+                ok, what, sample_bases, cpu_dt, used = oracle_check(ow, args, O, 1)
+                entry["parity"] = bool(ok)
+                entry["parity_sample"] = "%s (%.1f Mbases) vs oracle/trew_oracle.c, %.1f s on 1 thread" % (what, sample_bases / 1e6, cpu_dt)
+                if not ok:
+                    out["parity"] = False
+                    out["parity_note"] += "; %s MISMATCH" % mode
+            ow.close()
+            others.append(entry)
+        out["other_configs"] = others
 
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    for ptr in (to_free or [d_words]):
-        t.free(ptr)
-    t.close()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0 and out.get("parity") is False:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TREW_HIP_ABI_VERSION 1
+#define TREW_HIP_ABI_VERSION 2
 
 /* scan modes: which per-read driver of the reference is reproduced */
 enum {
@@ -54,7 +54,9 @@ enum {
     TREW_FLAG_NO_FILTER = 1, /* skip the bucket-bound prefilter: every k is a candidate (exact path only) */
     TREW_FLAG_DEBUG_NO_EMIT = 2, /* timing experiments only: drop every table update (results are empty) */
     TREW_FLAG_DEBUG_NO_KLOOP = 4, /* timing experiments only: prefilter without its k loop (nothing is flagged) */
-    TREW_FLAG_DEBUG_POISON_LDS = 32 /* tests: the exact kernel starts from garbage-filled LDS */
+    TREW_FLAG_DEBUG_POISON_LDS = 32, /* tests: the exact kernel starts from garbage-filled LDS */
+    TREW_FLAG_NO_TIMING = 64 /* no HIP events around the kernels (trew_hip_last_timing is unavailable): for hosts that
+                                submit ~10^4 small batches a second and are bound by API calls */
 };
 
 /* Replaces the eight configuration globals MIN_MER ... HIGH_BASELINE
@@ -77,7 +79,11 @@ typedef struct {
 /* Replaces QueueData / PairQueueData + LocationVector (kmer.h:73, 93-103): one
  * chunk of reads handed to the consumer.  The caller keeps ownership of every
  * pointer until trew_hip_wait(slot) returns.  With on_device != 0 the pointers
- * are device pointers and nothing is copied. */
+ * are device pointers and nothing is copied.
+ * Host batches: when the three arrays lie back to back in one (pinned) buffer, laid out [offsets][lengths][words]
+ * (lengths == offsets + n_reads, words == lengths + n_reads) or [words][offsets][lengths] (offsets == words +
+ * n_words, lengths == offsets + n_reads), the batch is shipped with a single asynchronous copy; any other layout
+ * works too and costs three. */
 typedef struct {
     const uint32_t *words;    /* packed triples                                               */
     uint64_t n_words;
@@ -106,7 +112,9 @@ typedef struct trew_hip_ctx trew_hip_ctx;
  * trew.cpp:382-406: allocates streams, device buffers, the count table. */
 int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out);
 void trew_hip_destroy(trew_hip_ctx *ctx);
-const char *trew_hip_last_error(const trew_hip_ctx *ctx); /* ctx may be NULL: last init error */
+/* Text of the calling thread's last failing call (several host threads may share a context, one slot each);
+ * ctx may be NULL: last trew_hip_init error. */
+const char *trew_hip_last_error(const trew_hip_ctx *ctx);
 
 /* Replaces one pop+process iteration of buffer_task* (kmer.cpp:106-177):
  * asynchronously copies the batch (unless on_device), runs the prefilter and
@@ -123,6 +131,30 @@ int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows, uint64_t 
 int trew_hip_reset_tables(trew_hip_ctx *ctx);
 /* Adds rows (e.g. another rank's tables) into the device tables. */
 int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_rows);
+
+/* ---- cross-GPU reduction of the tables; the reference's only counterpart is the
+ * single-threaded map merge of process_output, kmer.cpp:1486-1515, and the cross-file merge, trew.cpp:454-467 ----
+ * Counts are sums, so a table is reduced by adding every other table's rows into it.
+ *
+ * trew_hip_collect_device: device-to-device form of trew_hip_collect(table = -1) for an exchange that never
+ * leaves HBM (one process per GPU: the caller all_gathers d_rows with RCCL).  d_rows is a device buffer of cap
+ * rows on the context's GPU; *n_rows receives the number of rows there are (nothing is written past cap, call
+ * again with a larger buffer).  Rows may repeat a key (spilled rows); every consumer below merges by adding.
+ * trew_hip_add_rows_device: trew_hip_add_rows for rows that already live on the context's GPU.
+ * trew_hip_merge: one process driving several GPUs (`trew --devices 0,1,...`): adds every row of src's tables
+ * into dst's tables with one peer copy (xGMI between two GPUs); src is left unchanged. */
+int trew_hip_collect_device(trew_hip_ctx *ctx, trew_hip_row *d_rows, uint64_t cap, uint64_t *n_rows);
+int trew_hip_add_rows_device(trew_hip_ctx *ctx, const trew_hip_row *d_rows, uint64_t n_rows);
+int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src);
+
+/* Fill state of the device tables (a snapshot; does not wait for running batches).  The reference's hash maps
+ * grow without bound (absl::flat_hash_map, kmer.h:79); the device table has a fixed number of slots, rows that
+ * find their partition full go to a spill log of spill_capacity rows, and only a full log loses counts (then
+ * trew_hip_collect fails).  A host that scans unbounded input calls this between batches and, when
+ * used_slots nears total_slots or spilled_rows > 0, drains: trew_hip_collect, keep the rows, trew_hip_reset_tables.
+ * Any pointer may be NULL. */
+int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *total_slots, uint64_t *spilled_rows,
+                            uint64_t *spill_capacity);
 
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for
  * TREW_MODE_SEGMENT the (k_high, k_low, MAX_SEQ at k_high, MAX_SEQ at k_low)

@@ -29,14 +29,18 @@ def _rot_rc(k, w):
     return rot_seq(revcomp(w, k), k)
 
 
+_U32 = 0xFFFFFFFF  # ResultMap values are uint32_t (kmer.h:79): every += up to here wraps modulo 2^32
+
+
 def _fold_one(forward, backward, both, min_mer):
     """One baseline of process_output: kmer.cpp:1518-1579 + filter 1585-1605.
     Returns {(k, word): [forward, backward, both]} (backward == -1 marks a
     palindromic class, kmer.cpp:1531)."""
-    fwd = dict(forward)
+    fwd = {key: cnt & _U32 for key, cnt in forward.items()}
+    both = {key: cnt & _U32 for key, cnt in both.items()}
     for (k, w), cnt in backward.items():  # kmer.cpp:1518-1523
         key = (k, _rot_rc(k, w))
-        fwd[key] = fwd.get(key, 0) + cnt
+        fwd[key] = (fwd.get(key, 0) + cnt) & _U32
     final = {}
     for (k, w), cnt in fwd.items():  # kmer.cpp:1526-1540
         t = _rot_rc(k, w)

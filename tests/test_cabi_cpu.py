@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(capi.EXPORTED_SYMBOLS)
     for s in declared:
         assert getattr(lib, s) is not None
-    assert lib.trew_hip_abi_version() == 1
+    assert lib.trew_hip_abi_version() == 2
 
 
 def test_pack_reads_matches_codes_table():
@@ -63,3 +63,23 @@ def test_compute_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(capi.TrewHipError):
         capi.TrewHip()
+
+
+def test_pack_reads_every_byte_value_all_simd_widths():
+    """All 256 byte values at every alignment through the 64-, 32- and 1-base packers (codes[], kmer.cpp:14-31)."""
+    import random
+
+    rnd = random.Random(3)
+    reads = [bytes(range(256)) * 2, bytes(rnd.randrange(256) for _ in range(1000))]
+    reads += [bytes(rnd.choice(b"ACGTacgtNn\r") for _ in range(n)) for n in (31, 32, 33, 63, 64, 65, 95, 96, 127, 128, 129, 191, 200)]
+    reads = [r.replace(b"\n", b"X") for r in reads]  # pack_reads() joins with newlines
+    words, offs, lens = capi.pack_reads(reads)
+    for r, off, n in zip(reads, offs, lens):
+        assert n == len(r)
+        for i, ch in enumerate(r):
+            j, b = divmod(i, 32)
+            lo = (int(words[off + 3 * j]) >> b) & 1
+            hi = (int(words[off + 3 * j + 1]) >> b) & 1
+            nm = (int(words[off + 3 * j + 2]) >> b) & 1
+            c = O.code(chr(ch)) if ch < 128 else -1
+            assert (nm, lo, hi) == ((1, 0, 0) if c < 0 else (0, c & 1, c >> 1)), (ch, i)

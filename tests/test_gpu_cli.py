@@ -124,12 +124,91 @@ def test_cli_long(tmp_path):
     assert len(want) > 6
 
 
-def test_cli_rejects_long_read_in_short_mode(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--serial_reader"], ["-t", "6"]])
+def test_cli_rejects_long_read_in_short_mode(tmp_path, extra):
+    """kmer.cpp:1006-1009: message on stderr, exit status 1 -- from a worker thread while other threads hold live
+    HIP streams (the process leaves through _exit; it must neither hang nor crash)."""
+    buf, st, nd = capi.synth_short_ascii(3, 0, 40000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    reads.insert(30000, b"ACGT" * 300)
     a = str(tmp_path / "x.fastq")
-    write_fastq(a, [b"ACGT" * 300])
-    r = subprocess.run([TREW, "short", "5", "32", a], capture_output=True, text=True, timeout=120)
+    write_fastq(a, reads)
+    r = subprocess.run([TREW, "short", "5", "32", a, *extra], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1
     assert "This mode is designed for short-read sequencing. Please use 'trew long'." in r.stderr
+
+
+def test_cli_block_parallel_reader_equals_serial_reader(tmp_path):
+    """Plain FASTQ goes through the block-parallel reader (mapped file, 4 MiB blocks claimed by the worker threads);
+    --serial_reader forces the reference-shaped single reader.  Same bytes on stdout, several blocks, odd line
+    lengths, reads that straddle block borders, with and without a final newline."""
+    import random
+
+    rnd = random.Random(12)
+    buf, st, nd = capi.synth_short_ascii(20250218, 1000, 50000, 150)
+    reads = [buf[s:e + 1][: rnd.choice([150, 150, 150, 149, 101, 36, 0, 7])] for s, e in zip(st, nd)]
+    a = str(tmp_path / "a.fastq")
+    write_fastq(a, reads)
+    assert os.path.getsize(a) > 2 * (1 << 22)
+    want = expected([(a, O.run_short(O.OracleParams(), reads))], 5)
+    ref = run("short", "5", "32", a, "--serial_reader", "-t", "3")
+    assert ref == want
+    for t in ("2", "4", "9", "17"):
+        assert run("short", "5", "32", a, "-t", t) == want
+    assert run("short", "5", "32", a, "-t", "3", "--batch_mib", "1") == want  # several batches per worker
+    data = open(a, "rb").read()
+    b = str(tmp_path / "b.fastq")
+    open(b, "wb").write(data[:-1])  # the last quality line has no newline: nothing changes
+    assert run("short", "5", "32", b, "-t", "4") == [x.replace(os.path.realpath(a), os.path.realpath(b)) for x in want]
+    r = subprocess.run([TREW, "short", "5", "32", a, "-t", "5", "--stats"], capture_output=True, text=True, timeout=300)
+    assert "block-parallel reader" in r.stderr and "%d reads" % len(reads) in r.stderr
+
+
+def test_cli_long_block_parallel(tmp_path):
+    from test_gpu_parity import _long_reads
+
+    reads = _long_reads(78, 3000)  # ~ 2 blocks, reads of up to 12 kb straddle the border; short ones are dropped (kmer.cpp:1184)
+    a = str(tmp_path / "long.fastq")
+    write_fastq(a, reads)
+    assert os.path.getsize(a) > (1 << 22)
+    want = expected([(a, O.run_long(O.OracleParams(), reads))], 5)
+    assert run("long", "5", "32", a, "-t", "4") == want
+    assert run("long", "5", "32", a, "-t", "4", "--serial_reader") == want
+
+
+def test_cli_tiny_table_is_drained_not_lost(tmp_path):
+    """The device count table is fixed-size where the reference's hash maps grow (kmer.h:79).  With a 4096-slot table
+    these reads cannot fit: the host must empty the table into memory mid-file (trew_hip_table_pressure ->
+    collect -> reset) and still print the oracle's CSV."""
+    from helpers import edge_reads, mixed_segments
+
+    reads = []
+    for rep in range(12):  # several 4 MiB blocks, each with far more keys than the table has slots
+        reads += [r for r in edge_reads(11 + rep) if len(r) <= 1000] + mixed_segments(5 + rep, 1500, [150, 200, 300])
+    a = str(tmp_path / "keys.fastq")
+    write_fastq(a, reads)
+    tables = O.run_short(O.OracleParams(), reads)
+    assert sum(len(v) for v in tables.values()) > 3 * 4096
+    want = expected([(a, tables)], 5)
+    for extra in (["-t", "2", "--batch_mib", "1"], ["-t", "2", "--serial_reader"]):  # one worker: the drain points are deterministic
+        r = subprocess.run([TREW, "short", "5", "32", a, "--table_log2_slots", "12", "--stats", *extra], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.splitlines() == want
+        drains = int(r.stderr.split(" table drain(s)")[0].split()[-1])
+        assert drains >= 1, r.stderr
+    assert run("short", "5", "32", a) == want  # default table: same output, no drain needed
+
+
+def test_cli_several_contexts_reduce_on_the_device(tmp_path):
+    """--devices LIST: one context per entry, worker threads spread over them, tables reduced with trew_hip_merge
+    (peer copy + add kernel) before they are collected.  One GPU here, so the list names it twice."""
+    buf, st, nd = capi.synth_short_ascii(20250218, 7, 50000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    a = str(tmp_path / "a.fastq")
+    write_fastq(a, reads)
+    want = expected([(a, O.run_short(O.OracleParams(), reads))], 5)
+    assert run("short", "5", "32", a, "--devices", "0,0", "-t", "5") == want
+    assert run("short", "5", "32", a, "--devices", "0,0,0", "-t", "4", "--serial_reader") == want
 
 
 def test_cli_bgzf_input(tmp_path):

@@ -246,6 +246,31 @@ def test_multi_slot_and_reset():
         assert {n: {k: 2 * c for k, c in want[n].items()} for n in want} == got
 
 
+def test_one_copy_batches_and_untimed_contexts():
+    """The [offsets][lengths][words] host layout (one H2D copy per batch) and TREW_FLAG_NO_TIMING (no HIP events):
+    what the `trew` host submits.  Many small batches back to back on two slots also exercise the exact kernel's
+    reset of the worklist counters (no memset between submits)."""
+    buf, st, nd = capi.synth_short_ascii(4, 0, 12000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)] + edge_reads(2)
+    want = O.run_short(O.OracleParams(), reads)
+    for flags in (0, T.FLAG_NO_TIMING):
+        with T.TrewHip(mode=T.MODE_SHORT, n_slots=2, max_batch_reads=1024, max_batch_words=1 << 17, flags=flags) as t:
+            for rep in range(2):
+                for j, i in enumerate(range(0, len(reads), 700)):
+                    slot = j % 2
+                    t.wait(slot)
+                    t.submit(t.host_batch(*capi.pack_reads(reads[i:i + 700]), contiguous=(j % 3 != 0)), slot)
+                if rep == 0:
+                    assert t.collect() == want
+            assert t.collect() == {n: {k: 2 * c for k, c in want[n].items()} for n in want}
+            if flags & T.FLAG_NO_TIMING:
+                with pytest.raises(T.TrewHipError):
+                    t.last_timing(0)
+            else:
+                a, b, nflag = t.last_timing(0)
+                assert a > 0 and b > 0 and 0 < nflag <= 700
+
+
 def test_empty_and_tiny_batches():
     with T.TrewHip(mode=T.MODE_SHORT) as t:
         t.submit_reads([])
@@ -579,26 +604,27 @@ def test_full_size_properties_config2():
     assert got == want
 
 
-def test_full_size_properties_pair_and_long():
-    """Configs 3 and 4 at bench size (10 M pairs of 2 x 150 bp; 200 k ONT-like reads = 3.1 Gbases):
-    sharding invariance and idempotence of the tables, and bit-exactness against the oracle on a
-    prefix small enough for the CPU."""
+def test_full_size_config3_pairs():
+    """BASELINE config 3 at full size (50 M pairs of 2 x 150 bp, device-generated, 6 GB of packed reads):
+    sharding invariance of the tables, and bit-exactness against the CPU oracle on a 30 k-pair prefix
+    (buffer_task_pair, kmer.cpp:268-745)."""
     L = 150
     stride = 3 * ((L + 31) // 32)
     seed = 20250218
-    npairs = 10_000_000
+    npairs = 50_000_000
     with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=2 * npairs, max_batch_words=16, table_log2_slots=20) as t:
         d = t.malloc(2 * npairs * stride * 4 + 64)
         t.synth_pair_device(seed, 0, npairs, L, d)
         t.submit(t.device_uniform_batch(d, 2 * npairs, L))
         t.wait()
         whole = t.collect()
-        assert sum(sum(v.values()) for v in whole.values()) > 10_000_000
+        assert sum(sum(v.values()) for v in whole.values()) > 50_000_000
         t.reset_tables()
         q = npairs // 5
-        for i in range(5):
-            t.submit(t.device_uniform_batch(d + 2 * i * q * stride * 4, 2 * q, L))
-            t.wait()
+        for i in range(5):  # other batch borders, other worklists, two streams
+            t.submit(t.device_uniform_batch(d + 2 * i * q * stride * 4, 2 * q, L), i % 2)
+        t.wait(0)
+        t.wait(1)
         assert t.collect() == whole
         m = 30_000  # pairs checked against the oracle
         t.reset_tables()
@@ -609,23 +635,39 @@ def test_full_size_properties_pair_and_long():
     b1, b2, st, nd = capi.synth_pair_ascii(seed, 0, m, L)
     assert got == O.run_pair(O.OracleParams(), [b1[s:e + 1] for s, e in zip(st, nd)], [b2[s:e + 1] for s, e in zip(st, nd)])
 
-    nlong = 200_000
+
+def test_full_size_config4_long_reads():
+    """BASELINE config 4 at full size (1 M ONT-like reads, N50 ~ 20 kb, 15.6 Gbases, 5.9 GB of packed reads):
+    idempotence and sharding invariance, and bit-exactness against the CPU oracle on the first 6 k reads of
+    this very workload (buffer_task_long, kmer.cpp:747-985)."""
+    seed = 20250218
+    nlong = 1_000_000
     with T.TrewHip(mode=T.MODE_LONG, slice_length=150, max_batch_reads=nlong, max_batch_words=16, table_log2_slots=20) as t:
         b, ptrs, bases = t.synth_long_device(seed, 0, nlong)
-        assert bases > 3_000_000_000
+        assert bases > 15_000_000_000
         t.submit(b)
         t.wait()
         whole = t.collect()
-        assert sum(sum(v.values()) for v in whole.values()) > 1_000_000
+        assert sum(sum(v.values()) for v in whole.values()) > 5_000_000
         t.submit(b)
         t.wait()
         assert t.collect() == {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        # oracle leg: a prefix of the same resident batch
+        m = 6_000
+        t.reset_tables()
+        t.submit(capi.Batch(b.words, b.n_words, b.offsets, b.lengths, 0, 0, m, 1, b.max_length))
+        t.wait()
+        got = t.collect()
         for p in ptrs:
             t.free(p)
-        # two halves generated separately (first_read offsets the counter-based generator)
+        buf, st, nd = capi.synth_long_ascii(seed, 0, m)
+        want = O.run_long(O.OracleParams(), [buf[s:e + 1] for s, e in zip(st, nd)])
+        assert got == want
+        assert sum(len(v) for v in want.values()) > 100 and len(want["backward_high"]) > 0 and len(want["forward_high"]) > 0
+        # four quarters generated separately (first_read offsets the counter-based generator)
         t.reset_tables()
-        for first in (0, nlong // 2):
-            b2, ptrs2, _ = t.synth_long_device(seed, first, nlong // 2)
+        for i in range(4):
+            b2, ptrs2, _ = t.synth_long_device(seed, i * (nlong // 4), nlong // 4)
             t.submit(b2)
             t.wait()
             for p in ptrs2:
@@ -720,3 +762,83 @@ def test_results_do_not_depend_on_lds_residue():
         t.submit_reads(lr)
         t.wait()
         assert t.collect() == O.run_long(O.OracleParams(slice_len=150), lr)
+
+
+def test_table_reduction_entry_points():
+    """trew_hip_collect_device / trew_hip_add_rows_device / trew_hip_merge / trew_hip_table_pressure: two contexts on
+    this GPU scan two halves of a read set; merging one into the other must give the tables of the whole set."""
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 30000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(), reads)
+    half = len(reads) // 2
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=half + 8, max_batch_words=1 << 22) as a, \
+            T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=half + 8, max_batch_words=1 << 22) as b:
+        a.submit_reads(reads[:half])
+        b.submit_reads(reads[half:])
+        a.wait()
+        b.wait()
+        used, total, spilled, spill_cap = a.table_pressure()
+        assert used == sum(len(v) for v in a.collect().values()) and total == 1 << 20 and spilled == 0 and spill_cap >= 1 << 16
+        part_b = b.collect()
+        # (1) in-library merge (peer copy + add kernel); the source is left unchanged
+        a.merge_from(b)
+        assert a.collect() == want
+        assert b.collect() == part_b
+        # (2) the same through a caller-owned device buffer (what the RCCL exchange does with torch tensors;
+        # torch itself is kept out of this process: tests/test_gpu_rccl.py covers that side)
+        a.reset_tables()
+        a.submit_reads(reads[:half])
+        a.wait()
+        row_bytes = capi.ROW_DTYPE.itemsize
+        small = a.malloc(4 * row_bytes)
+        n = b.collect_device(small, 4)
+        assert n == sum(len(v) for v in part_b.values()) > 4  # too small: the size comes back, nothing is written past cap
+        a.free(small)
+        d_rows = a.malloc(n * row_bytes)
+        assert b.collect_device(d_rows, n) == n
+        got_rows = a.d2h(d_rows, n * row_bytes).view(capi.ROW_DTYPE)
+        assert capi.rows_to_tables(got_rows) == part_b
+        a.add_rows_device(d_rows, n)
+        assert a.collect() == want
+        # a row that cannot be a table row is refused loudly
+        bad = np.zeros(1, dtype=capi.ROW_DTYPE)
+        bad["k"], bad["table"], bad["count"] = 99, 0, 1
+        a._chk(a.lib.trew_hip_memcpy_h2d(a.ctx, d_rows, bad.ctypes.data, row_bytes), "h2d")
+        with pytest.raises(T.TrewHipError):
+            a.add_rows_device(d_rows, 1)
+        a.free(d_rows)
+
+
+def test_wide_keys_shared_by_a_class_and_its_reverse_complement():
+    """k_mer_target_128 (kmer.cpp:2019-2142) keys by MIN(w, rot(rc(w))): a read that holds a k >= 33 repeat and its
+    reverse complement emits ONE key from two classes of one wave.  The wide table's claim/ready protocol must never
+    make a lane wait for a sibling lane (emit_k merges equal keys first): exact, and fast."""
+    import random
+    import time
+
+    from helpers import periodic
+
+    rnd = random.Random(4242)
+    reads = []
+    for i in range(1500):
+        k = rnd.randint(33, 64)
+        unit = "".join(rnd.choice("ACGT") for _ in range(k))
+        rc = _revcomp(unit.encode()).decode()
+        n = 1000
+        cut = rnd.choice([640, 700, 760])
+        reads.append((periodic(unit, cut, rnd.randint(0, k - 1)) + periodic(rc, n - cut, rnd.randint(0, k - 1))).encode())
+    want = O.run_short(O.OracleParams(max_mer=64), reads)
+    both = want["both_low"]
+    assert sum(1 for (k, _) in both if k > 32) > 500  # the case is really there: wide strand-canonical keys
+    with T.TrewHip(mode=T.MODE_SHORT, max_mer=64, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22) as t:
+        t.submit_reads(reads)  # warm-up (module load)
+        t.wait()
+        t.reset_tables()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            t.submit_reads(reads)
+            t.wait()
+        dt = time.perf_counter() - t0
+        got = t.collect()
+    assert got == {n: {key: 3 * c for key, c in want[n].items()} for n in want}
+    assert dt < 5.0, "wide-table inserts took %.1f s: a lane is spinning on a sibling" % dt

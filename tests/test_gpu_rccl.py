@@ -1,0 +1,81 @@
+"""The RCCL path of the cross-GPU table reduction on ONE GPU: backend "nccl" with world size 1, collectives really
+issued (trew_amd.dist.allreduce_table_device(force_collectives=True)).  Runs in a child process because the nccl
+process group has to be created before any other GPU work of the process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", str(29800 + os.getpid() %% 150))
+os.environ["RANK"] = "0"
+os.environ["WORLD_SIZE"] = "1"
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))   # RCCL, before anything else touches the GPU
+import numpy as np
+import oracle as O
+import trew_amd as T
+from trew_amd import capi
+from trew_amd.dist import allreduce_table_device
+
+dev = torch.device("cuda", 0)
+buf, st, nd = capi.synth_short_ascii(20250218, 0, 30000, 150)
+reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+want = O.run_short(O.OracleParams(), reads)
+with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22) as t:
+    t.submit_reads(reads)
+    t.wait()
+    merged = allreduce_table_device(t, dev, force_collectives=True)   # all_gather(sizes) + all_gather(rows) through RCCL
+    assert capi.rows_to_tables(merged) == want, "tables changed by the RCCL exchange"
+    # the gathered rows are usable as another rank's contribution: add them once more -> every count doubles
+    n = len(merged)
+    rows = torch.from_numpy(np.ascontiguousarray(merged).view(np.int64).reshape(n, 4)).to(dev)
+    out = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, rows)
+    torch.cuda.synchronize()
+    t.add_rows_device(out.data_ptr(), n)
+    assert t.collect() == {name: {k: 2 * c for k, c in want[name].items()} for name in want}
+    # an all_reduce on device memory too (the MAX over ranks of the timed region in bench.py)
+    x = torch.tensor([3.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    assert float(x.item()) == 3.5
+print("backend", dist.get_backend(), "rows", n)
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_WORLD1_OK")
+'''
+
+
+def test_rccl_collectives_on_one_gpu():
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "backend nccl" in r.stdout
+
+
+def test_bench_two_ranks_one_gpu_gloo_rehearsal():
+    """bench.py's N > 1 code path (rank-sharded reads, barrier, reduction inside the timed region, MAX over ranks)
+    with two ranks sharing this GPU over gloo -- RCCL itself refuses two ranks on one device."""
+    import json
+
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29950 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--backend", "gloo", "--reads", "2000000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["table_rows"] > 1000

@@ -8,6 +8,7 @@ from . import capi  # noqa: F401
 from .capi import (  # noqa: F401
     FLAG_NO_FILTER,
     FLAG_DEBUG_POISON_LDS,
+    FLAG_NO_TIMING,
     MODE_LONG,
     MODE_PAIR,
     MODE_SEGMENT,

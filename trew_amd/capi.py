@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("TREW_HIP_LIB") or os.path.join(_HERE, "lib", "libtrew
 MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
 FLAG_NO_FILTER = 1
 FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (tests)
+FLAG_NO_TIMING = 64  # no HIP events per submit (last_timing unavailable)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
 
 # every symbol include/trew_hip.h declares
@@ -28,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "trew_hip_malloc", "trew_hip_free", "trew_hip_memcpy_h2d", "trew_hip_memcpy_d2h", "trew_hip_abi_version",
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
     "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
+    "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
 )
 
 
@@ -98,6 +100,10 @@ def load():
     lib.trew_hip_collect.argtypes = [vp, i32, C.POINTER(Row), u64, C.POINTER(u64)]
     lib.trew_hip_reset_tables.argtypes = [vp]
     lib.trew_hip_add_rows.argtypes = [vp, C.POINTER(Row), u64]
+    lib.trew_hip_collect_device.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    lib.trew_hip_add_rows_device.argtypes = [vp, vp, u64]
+    lib.trew_hip_merge.argtypes = [vp, vp]
+    lib.trew_hip_table_pressure.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64]
     lib.trew_hip_filter_masks.argtypes = [vp, C.POINTER(Batch), vp, i32]
     lib.trew_hip_last_timing.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(u64)]
@@ -219,10 +225,17 @@ class TrewHip:
             raise TrewHipError("%s failed (%d): %s" % (what, rc, self.lib.trew_hip_last_error(self.ctx).decode()))
 
     # ---- batches ----
-    def host_batch(self, words, offsets, lengths):
+    def host_batch(self, words, offsets, lengths, contiguous=False):
+        """contiguous: one buffer laid out [offsets][lengths][words], which trew_hip_submit ships with a single copy."""
         words = np.ascontiguousarray(words, dtype=np.uint32)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
         lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if contiguous:
+            n = len(offsets)
+            buf = np.concatenate([offsets, lengths, words])
+            b = Batch(buf.ctypes.data + 8 * n, len(words), buf.ctypes.data, buf.ctypes.data + 4 * n, 0, 0, n, 0, 0)
+            b._keep = (buf,)
+            return b
         b = Batch(words.ctypes.data, len(words), offsets.ctypes.data, lengths.ctypes.data, 0, 0, len(offsets), 0, 0)
         b._keep = (words, offsets, lengths)
         return b
@@ -269,6 +282,26 @@ class TrewHip:
         if len(rows):
             self._chk(self.lib.trew_hip_add_rows(self.ctx, C.cast(rows.ctypes.data, C.POINTER(Row)), len(rows)),
                       "trew_hip_add_rows")
+
+    def collect_device(self, d_rows, cap):
+        """Compact every table into the device buffer d_rows (cap rows of ROW_DTYPE.itemsize bytes); returns the row count
+        (which may exceed cap: nothing is written past cap then)."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_collect_device(self.ctx, d_rows, cap, C.byref(n)), "trew_hip_collect_device")
+        return int(n.value)
+
+    def add_rows_device(self, d_rows, n_rows):
+        self._chk(self.lib.trew_hip_add_rows_device(self.ctx, d_rows, n_rows), "trew_hip_add_rows_device")
+
+    def merge_from(self, other):
+        """Add every row of `other`'s tables (another context, same or another GPU) into this context's tables."""
+        self._chk(self.lib.trew_hip_merge(self.ctx, other.ctx), "trew_hip_merge")
+
+    def table_pressure(self):
+        """(used_slots, total_slots, spilled_rows, spill_capacity) -- a snapshot."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        self._chk(self.lib.trew_hip_table_pressure(self.ctx, *[C.byref(x) for x in v]), "trew_hip_table_pressure")
+        return tuple(int(x.value) for x in v)
 
     def segment_results(self, n_reads, slot=0):
         kh = np.zeros(n_reads, dtype=np.int32)

@@ -2,8 +2,12 @@
 // htslib) input.  A BGZF file is a series of independent gzip members of <= 64 KiB, each carrying
 // its compressed size in a 'BC' extra subfield, so members can be inflated concurrently; gzread
 // (what the reference uses, kmer.h:157-204) inflates the same bytes on one thread.  Plain gzip files
-// do not have the subfield and keep going through zlib's gzread.
+// do not have the subfield and keep going through zlib's gzread.  A file may also mix the two (`cat a.bgz b.gz`,
+// which gzread reads without trouble): when a member without the subfield is met after BGZF members, the rest of
+// the file is handed to zlib from that offset.
 #pragma once
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -25,13 +29,13 @@ public:
     static bool sniff(const char *file_name) {
         FILE *f = fopen(file_name, "rb");
         if (!f) return false;
-        unsigned char h[18];
-        const size_t n = fread(h, 1, sizeof(h), f);
+        std::vector<unsigned char> h;
+        const int bs = read_header(f, h);
         fclose(f);
-        return n == sizeof(h) && block_size(h) > 0;
+        return bs > 0;
     }
 
-    BgzfReader(const char *file_name, int n_threads) {
+    BgzfReader(const char *file_name, int n_threads) : name_(file_name) {
         fp_ = fopen(file_name, "rb");
         if (!fp_) {
             fail("cannot open file");
@@ -51,6 +55,7 @@ public:
         cv_space_.notify_all();
         if (producer_.joinable()) producer_.join();
         for (auto &t : workers_) t.join();
+        if (tail_) gzclose(tail_);
         if (fp_) fclose(fp_);
     }
     bool ok() const { return fp_ != nullptr; }
@@ -59,6 +64,20 @@ public:
     int read(char *buffer, int length) {
         int got = 0;
         while (got < length) {
+            if (tail_) {  // the rest of the file is ordinary gzip: zlib reads it, as the reference does
+                const int r = gzread(tail_, buffer + got, (unsigned) (length - got));
+                if (r < 0) {
+                    int e;
+                    fail(std::string("gzip tail: ") + gzerror(tail_, &e));
+                    return -1;
+                }
+                got += r;
+                if (r == 0 || gzeof(tail_)) {
+                    eof_ = gzeof(tail_) != 0;
+                    if (r == 0) return got;
+                }
+                continue;
+            }
             if (cur_pos_ == cur_.size()) {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_out_.wait(lk, [&] { return stop_ || !error_.empty() || done_.count(next_out_) || (produced_all_ && next_out_ == n_blocks_); });
@@ -66,6 +85,19 @@ public:
                 if (stop_) return got;
                 auto it = done_.find(next_out_);
                 if (it == done_.end()) {  // every block consumed
+                    if (tail_offset_ >= 0) {  // ... and a plain gzip member follows
+                        const long long off = tail_offset_;
+                        tail_offset_ = -1;
+                        lk.unlock();
+                        const int fd = open(name_.c_str(), O_RDONLY);
+                        if (fd < 0 || lseek(fd, (off_t) off, SEEK_SET) != (off_t) off || !(tail_ = gzdopen(fd, "r"))) {
+                            if (fd >= 0) close(fd);
+                            fail("cannot reopen the file for its gzip tail");
+                            return -1;
+                        }
+                        gzbuffer(tail_, 1 << 20);
+                        continue;
+                    }
                     eof_ = true;
                     return got;
                 }
@@ -95,12 +127,27 @@ private:
         uint64_t seq;
         std::vector<unsigned char> comp;  // one whole member
     };
-    // total size of the member whose first 18 bytes are h, or 0 when it is not a BGZF header
-    static int block_size(const unsigned char *h) {
-        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
-        const int xlen = h[10] | (h[11] << 8);
-        if (xlen < 6 || h[12] != 'B' || h[13] != 'C' || h[14] != 2 || h[15] != 0) return 0;
-        return (h[16] | (h[17] << 8)) + 1;
+    // Reads one gzip member header (the 12 fixed bytes + the extra field) from f into h.  Returns the total size
+    // of the member when the extra field carries a 'BC' subfield (RFC 1952 2.3.1.1: any position among the
+    // subfields), 0 when the bytes are a gzip header without it, -1 when they are not a gzip header at all,
+    // -2 at a clean end of file, -3 when the file ends inside the header.
+    static int read_header(FILE *f, std::vector<unsigned char> &h) {
+        h.resize(12);
+        const size_t n = fread(h.data(), 1, 12, f);
+        if (n == 0) return -2;
+        if (n < 2 || h[0] != 0x1f || h[1] != 0x8b) return -1;
+        if (n < 10) return -3;  // the magic, then the file ends inside the header
+        if (h[2] != 8 || !(h[3] & 4)) return 0;
+        if (n < 12) return -3;
+        const size_t xlen = (size_t) h[10] | ((size_t) h[11] << 8);
+        h.resize(12 + xlen);
+        if (fread(h.data() + 12, 1, xlen, f) != xlen) return -3;
+        for (size_t p = 12; p + 4 <= 12 + xlen;) {
+            const size_t slen = (size_t) h[p + 2] | ((size_t) h[p + 3] << 8);
+            if (h[p] == 'B' && h[p + 1] == 'C' && slen == 2 && p + 6 <= 12 + xlen) return ((int) h[p + 4] | ((int) h[p + 5] << 8)) + 1;
+            p += 4 + slen;
+        }
+        return 0;
     }
     void fail(const std::string &msg) {
         std::lock_guard<std::mutex> lk(m_);
@@ -111,20 +158,30 @@ private:
     }
     void produce() {
         uint64_t seq = 0;
+        std::vector<unsigned char> h;
         for (;;) {
-            unsigned char h[18];
-            const size_t n = fread(h, 1, sizeof(h), fp_);
-            if (n == 0) break;  // clean end of file
-            const int bs = n == sizeof(h) ? block_size(h) : 0;
-            if (bs < 26) {
-                fail("not a BGZF member (truncated or mixed gzip file)");
+            const long long at = ftello(fp_);
+            const int bs = read_header(fp_, h);
+            if (bs == -2) break;  // clean end of file
+            if (bs == -1) break;  // not gzip: trailing garbage, which gzread ignores as well
+            if (bs == -3) {
+                fail("truncated BGZF member");
+                return;
+            }
+            if (bs == 0) {        // a gzip member without the BC subfield: the rest goes through zlib
+                std::lock_guard<std::mutex> lk(m_);
+                tail_offset_ = at;
+                break;
+            }
+            if ((size_t) bs < h.size() + 8) {
+                fail("corrupt BGZF member (size field smaller than its header)");
                 return;
             }
             Job j;
             j.seq = seq++;
             j.comp.resize((size_t) bs);
-            memcpy(j.comp.data(), h, sizeof(h));
-            if (fread(j.comp.data() + sizeof(h), 1, (size_t) bs - sizeof(h), fp_) != (size_t) bs - sizeof(h)) {
+            memcpy(j.comp.data(), h.data(), h.size());
+            if (fread(j.comp.data() + h.size(), 1, (size_t) bs - h.size(), fp_) != (size_t) bs - h.size()) {
                 fail("truncated BGZF member");
                 return;
             }
@@ -166,6 +223,10 @@ private:
             }
             const uint32_t isize = (uint32_t) c[n - 4] | ((uint32_t) c[n - 3] << 8) | ((uint32_t) c[n - 2] << 16) | ((uint32_t) c[n - 1] << 24);
             const uint32_t crc = (uint32_t) c[n - 8] | ((uint32_t) c[n - 7] << 8) | ((uint32_t) c[n - 6] << 16) | ((uint32_t) c[n - 5] << 24);
+            if (isize > 65536u) {  // a BGZF member holds at most 64 KiB: never allocate from a corrupt trailer
+                fail("corrupt BGZF member (uncompressed size above 64 KiB)");
+                return;
+            }
             std::vector<unsigned char> out(isize);
             if (isize) {
                 z_stream zs;
@@ -194,7 +255,10 @@ private:
     }
 
     static constexpr uint64_t kWindow = 256;  // members in flight (<= 16 MiB of output)
+    std::string name_;
     FILE *fp_ = nullptr;
+    gzFile tail_ = nullptr;       // plain gzip remainder of a mixed file (consumer thread only)
+    long long tail_offset_ = -1;  // where it starts (set by the producer under m_)
     std::thread producer_;
     std::vector<std::thread> workers_;
     std::mutex m_;

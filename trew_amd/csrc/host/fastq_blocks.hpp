@@ -1,0 +1,118 @@
+// fastq_blocks.hpp -- block-parallel location of the sequence lines of a plain (uncompressed) FASTQ file.
+//
+// The reference finds sequence lines by counting newlines from the start of the file: the newline that makes
+// `num & 3 == 2` closes one (read_fastq_thread, kmer.cpp:987-1038), i.e. line number 1 mod 4 (0-based), whatever
+// the lines contain.  Here the mapped file is cut into fixed-size blocks that worker threads claim in file order.
+// A worker records the newlines of its block, learns how many newlines precede the block from its predecessor
+// (a chain of additions -- the only serial part), and reports the sequence lines that END in its block; a line
+// that starts in an earlier block is simply read from there, which is what the reference's carry-over of a split
+// line achieves.  Line numbering is exact: no record-boundary heuristics, the same reads as the serial reader.
+#pragma once
+#include <sys/mman.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace trew_host {
+
+// offsets (relative to p) of every '\n' in p[0, n), n < 2^32; returns how many
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline size_t scan_newlines_avx2(const char *p, size_t n, uint32_t *out) {
+    size_t cnt = 0, i = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; i + 64 <= n; i += 64) {
+        const uint32_t m0 = (uint32_t) _mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *) (p + i)), nl));
+        const uint32_t m1 = (uint32_t) _mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *) (p + i + 32)), nl));
+        uint64_t m = ((uint64_t) m1 << 32) | m0;
+        while (m) {
+            out[cnt++] = (uint32_t) (i + (size_t) __builtin_ctzll(m));
+            m &= m - 1;
+        }
+    }
+    for (; i < n; i++)
+        if (p[i] == '\n') out[cnt++] = (uint32_t) i;
+    return cnt;
+}
+#endif
+inline size_t scan_newlines(const char *p, size_t n, uint32_t *out) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) return scan_newlines_avx2(p, n, out);
+#endif
+    size_t cnt = 0;
+    for (const char *q = (const char *) memchr(p, '\n', n); q; q = (const char *) memchr(q + 1, '\n', (size_t) (p + n - q - 1))) out[cnt++] = (uint32_t) (q - p);
+    return cnt;
+}
+
+struct BlockScan {
+    const char *base = nullptr;
+    size_t size = 0, block = 0, n_blocks = 0;
+    std::atomic<size_t> next{0};
+    // published by the worker of block b once its predecessor's values are known:
+    // lines_end[b] = newlines in [0, end of block b) (-1: not yet known);
+    // last_nl[b]   = offset of the last newline before the end of block b (-1: none).
+    std::unique_ptr<std::atomic<int64_t>[]> lines_end;
+    std::unique_ptr<int64_t[]> last_nl;
+    bool populate = false;  // base is a page-aligned file mapping: pre-fault each block when it is claimed
+
+    void init(const char *base_, size_t size_, size_t block_) {
+        base = base_;
+        size = size_;
+        block = block_;
+        n_blocks = (size + block - 1) / block;
+        lines_end.reset(new std::atomic<int64_t>[n_blocks]);
+        last_nl.reset(new int64_t[n_blocks]);
+        for (size_t i = 0; i < n_blocks; i++) lines_end[i].store(-1, std::memory_order_relaxed);
+        next.store(0);
+    }
+
+    // Claims the next block; false when none is left.  st / nd receive the inclusive byte ranges [st, nd] (offsets
+    // into the file, the LocationVector convention of kmer.h:73) of the sequence lines whose closing newline lies
+    // in the block; nl is scratch for the block's newline offsets (at least `block` entries).
+    bool claim(std::vector<uint32_t> &nl, std::vector<int64_t> &st, std::vector<int64_t> &nd) {
+        const size_t b = next.fetch_add(1);
+        if (b >= n_blocks) return false;
+        if (nl.size() < block) nl.resize(block);
+        const size_t lo = b * block, hi = lo + block < size ? lo + block : size;
+        if (populate) {
+            // map the block's pages with one call instead of a page fault per 64 KiB of a cold mapping (Linux >= 5.14;
+            // any failure just leaves the faults to happen)
+#ifdef MADV_POPULATE_READ
+            const size_t page = 4096, plo = lo & ~(page - 1);
+            (void) madvise(const_cast<char *>(base) + plo, hi - plo, MADV_POPULATE_READ);
+#endif
+        }
+        const size_t cnt = scan_newlines(base + lo, hi - lo, nl.data());
+        // the number of newlines before this block: a chain of additions through the blocks.  Blocks are claimed in
+        // file order, so every predecessor is already running on some thread, and it publishes right after its scan.
+        int64_t lines_before = 0, prev_nl = -1;
+        if (b > 0) {
+            int64_t v;
+            for (unsigned spin = 0; (v = lines_end[b - 1].load(std::memory_order_acquire)) < 0; spin++)
+                if (spin > 64) std::this_thread::yield();
+            lines_before = v;
+            prev_nl = last_nl[b - 1];
+        }
+        last_nl[b] = cnt ? (int64_t) (lo + nl[cnt - 1]) : prev_nl;
+        lines_end[b].store(lines_before + (int64_t) cnt, std::memory_order_release);
+        st.clear();
+        nd.clear();
+        // newline j of the block closes line number lines_before + j; sequence lines are the numbers 1 mod 4
+        for (size_t j = (size_t) ((1 - lines_before) & 3); j < cnt; j += 4) {
+            const int64_t start = j > 0 ? (int64_t) (lo + nl[j - 1]) + 1 : prev_nl + 1;
+            st.push_back(start);
+            nd.push_back((int64_t) (lo + nl[j]) - 1);
+        }
+        return true;
+    }
+};
+
+}  // namespace trew_host

@@ -68,6 +68,12 @@ bool check_ans_seq(const KmerSeq &seq, int min_mer) {
 
 static inline KmerSeq rot_rc(const KmerSeq &s) { return KmerSeq{s.k, get_rot_seq_128(reverse_complement_k(s.seq, s.k), s.k)}; }
 
+// The reference's maps hold uint32_t counts (ResultMap, kmer.h:79): the thread merge and the
+// backward -> forward fold add modulo 2^32 before the values are widened to FinalData<int64_t>
+// (kmer.cpp:1486-1549).  The device accumulates in 64 bits; addition modulo 2^32 is associative, so
+// truncating once here, at the per-file merge point, gives the reference's value even past a wrap.
+static inline int64_t wrap32(uint64_t v) { return (int64_t) (uint32_t) v; }
+
 // one baseline of process_output, kmer.cpp:1518-1579
 static FinalFastqData fold(const ResultMap &forward_in, const ResultMap &backward, const ResultMap &both) {
     ResultMap forward = forward_in;
@@ -83,19 +89,19 @@ static FinalFastqData fold(const ResultMap &forward_in, const ResultMap &backwar
             it = final_result.emplace(kseq, d).first;
         }
         if (kseq.seq == kv.first.seq)
-            it->second.forward = (int64_t) kv.second;
+            it->second.forward = wrap32(kv.second);
         else
-            it->second.backward = (int64_t) kv.second;
+            it->second.backward = wrap32(kv.second);
     }
     for (const auto &kv : both) {  // kmer.cpp:1541-1549
         auto it = final_result.find(kv.first);
         if (it != final_result.end()) {
-            it->second.both = (int64_t) kv.second;
+            it->second.both = wrap32(kv.second);
         } else {
             const KmerSeq t = rot_rc(kv.first);
             FinalData d;
             d.backward = (t.seq == kv.first.seq) ? -1 : 0;
-            d.both = (int64_t) kv.second;
+            d.both = wrap32(kv.second);
             final_result.emplace(kv.first, d);
         }
     }

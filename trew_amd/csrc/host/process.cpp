@@ -1,34 +1,62 @@
-// process.cpp -- per-file pipelines of the `trew` host: FASTQ/.gz chunk reader on the caller's
-// thread, packer threads that each own one device slot, device tables collected per file.
+// process.cpp -- per-file pipelines of the `trew` host: FASTQ decode on CPU threads, packing into
+// pinned buffers, one device slot (HIP stream) per worker thread, device tables collected per file.
 //
-// Shape of the reference (kmer.cpp:987-1476): one producer reading 4 MiB chunks (LENGTH,
-// kmer.h:8), sequence lines found by counting newlines (num & 3 == 2), a sequence line split
-// across two chunks carried over, pairs re-synchronised by read index; NUM_THREAD-1 consumers.
-// What differs: a consumer does not scan the reads itself -- it packs the chunk into pinned
-// memory and submits it to its own HIP stream (trew_hip_submit), so decode/pack of chunk i+1
-// overlaps the device scan of chunk i.
+// Two pipelines, same results:
+//
+//  * serial reader (gzip / BGZF input, paired files): the shape of the reference
+//    (kmer.cpp:987-1476) -- one producer reading 4 MiB chunks (LENGTH, kmer.h:8), sequence lines found by
+//    counting newlines (num & 3 == 2), a sequence line split across two chunks carried over, pairs
+//    re-synchronised by read index; NUM_THREAD-1 consumers.  A consumer does not scan the reads itself: it
+//    packs the chunk into pinned memory and submits it to its own HIP stream (trew_hip_submit), so
+//    decode/pack of chunk i+1 overlaps the device scan of chunk i.
+//
+//  * block-parallel reader (plain FASTQ, single-end and long mode): the file is mapped and cut into 4 MiB
+//    blocks that the NUM_THREAD-1 workers claim in file order.  A worker records the newlines of its block,
+//    learns the line number its block starts at from its predecessor (a chain of additions, the only serial
+//    part), and then packs the sequence lines that END in its block -- a line that starts in an earlier
+//    block is simply read from there, which is what the reference's carry-over achieves -- straight into its
+//    pinned buffers.  Line numbering is exact (no record-boundary heuristics): the same reads as
+//    read_fastq_thread, in any block order, since counts are sums.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 
 #include "bgzf_reader.hpp"
+#include "fastq_blocks.hpp"
 #include "trew_host.hpp"
 
 namespace trew_host {
 
 static const int LENGTH = 1 << 22;  // kmer.h:8
 static const int MAX_SEQ = 1000;    // kmer.h:10
+// Text a worker of the block-parallel reader gathers (over several 4 MiB blocks) before it submits one batch.  The
+// device scans a batch of this size in well under a millisecond; what a submit costs is its handful of HIP calls and
+// the stream's hand-overs (copy -> prefilter -> exact kernel), which at 4 MiB per batch and 15 workers were the whole
+// end-to-end time (tools/e2e_cli.py, profiles/r02/README.md).
+static const size_t kSubmitBytes = (size_t) 32 << 20;  // capacity; Config::batch_mib (<= 32) is what a batch is closed at
 
+// Errors follow the reference: message on stderr, exit status 1 (kmer.cpp:84-87, 1007-1008).  The other host
+// threads may be inside HIP calls on live streams at this moment; running atexit handlers and the HIP runtime's
+// teardown under them can hang, so the process leaves through _exit after flushing its own output.
 [[noreturn]] static void die(const char *msg) {
     fprintf(stderr, "%s\n", msg);
-    exit(EXIT_FAILURE);
+    fflush(stdout);
+    fflush(stderr);
+    _exit(EXIT_FAILURE);
 }
 
 // FileReader, kmer.h:157-204
@@ -64,31 +92,29 @@ struct FileReader {
     }
 };
 
+[[noreturn]] static void open_failed(const char *file_name) {  // kmer.cpp:1288-1289
+    fprintf(stderr, "File open failed: %s\n", file_name);
+    fflush(stdout);
+    fflush(stderr);
+    _exit(EXIT_FAILURE);
+}
+
 static FileReader open_reader(const char *file_name, bool is_gz) {
     FileReader r;
     r.is_gz = is_gz;
     if (is_gz && BgzfReader::sniff(file_name)) {
         const unsigned hw = std::thread::hardware_concurrency();
         r.bgzf = new BgzfReader(file_name, (int) std::min(8u, std::max(2u, hw / 2)));
-        if (!r.bgzf->ok()) {
-            fprintf(stderr, "File open failed: %s\n", file_name);
-            exit(EXIT_FAILURE);
-        }
+        if (!r.bgzf->ok()) open_failed(file_name);
         return r;
     }
     if (is_gz) {
         r.gz_fp = gzopen(file_name, "r");
-        if (!r.gz_fp) {  // kmer.cpp:1288-1289
-            fprintf(stderr, "File open failed: %s\n", file_name);
-            exit(EXIT_FAILURE);
-        }
+        if (!r.gz_fp) open_failed(file_name);
         gzbuffer(r.gz_fp, 1 << 20);
     } else {
         r.fp = fopen(file_name, "r");
-        if (!r.fp) {
-            fprintf(stderr, "File open failed: %s\n", file_name);
-            exit(EXIT_FAILURE);
-        }
+        if (!r.fp) open_failed(file_name);
     }
     return r;
 }
@@ -126,24 +152,44 @@ private:
 };
 
 struct Worker {
-    int dev_index = 0;  // index into Scanner::ctx
+    int dev_index = 0;  // index into Scanner::dev
     int slot = 0;
-    uint32_t *h_words = nullptr, *h_offsets = nullptr, *h_lengths = nullptr;
+    // one pinned allocation; a batch is laid out [offsets n][lengths n][words] (serial reader: n is known before
+    // packing) or [words][offsets n][lengths n] (block reader: reads accumulate), either of which trew_hip_submit
+    // ships with a single copy (include/trew_hip.h, trew_hip_batch)
+    uint32_t *h_buf = nullptr;
+    std::vector<uint32_t> tmp_off, tmp_len;  // block reader: offsets / lengths until the batch is closed
     uint64_t words_cap = 0, reads_cap = 0;
-    uint64_t reads = 0, bases = 0;
+    uint64_t reads = 0, bases = 0, submits = 0;
+    double t_scan = 0, t_wait = 0, t_pack = 0, t_submit = 0;  // seconds per phase, for --stats
+    std::vector<int64_t> st, nd;      // block-parallel reader: sequence lines of the current block
+    std::vector<uint32_t> nl;         // newline offsets of the current block
+};
+
+// one GPU: its context and the lock that keeps a table drain apart from running submits
+struct Device {
+    trew_hip_ctx *ctx = nullptr;
+    std::shared_mutex drain_mu;  // shared: trew_hip_submit; exclusive: collect + reset
 };
 
 struct Scanner {
     Config cfg;
     int mode = TREW_MODE_SHORT;
-    std::vector<trew_hip_ctx *> ctx;
+    std::vector<std::unique_ptr<Device>> dev;
     std::vector<Worker> workers;
     RunStats stats;
+    // rows drained from the device tables in the middle of a file (the reference's hash maps grow without
+    // bound; the device table is fixed-size, so it is emptied into host memory whenever it runs half full)
+    std::mutex pending_mu;
+    ResultMapData pending;
+    std::atomic<uint64_t> drains{0};
 };
 
-static void hip_die(trew_hip_ctx *ctx, const char *what) {
+[[noreturn]] static void hip_die(trew_hip_ctx *ctx, const char *what) {
     fprintf(stderr, "%s: %s\n", what, trew_hip_last_error(ctx));
-    exit(EXIT_FAILURE);
+    fflush(stdout);
+    fflush(stderr);
+    _exit(EXIT_FAILURE);
 }
 
 Scanner *scanner_create(const Config &cfg, int mode) {
@@ -154,7 +200,9 @@ Scanner *scanner_create(const Config &cfg, int mode) {
     const int ndev = (int) cfg.devices.size();
     const bool pair = mode == TREW_MODE_PAIR;
     const uint64_t reads_cap = (pair ? 2ull : 1ull) << 20;
-    const uint64_t words_cap = 3ull * ((uint64_t) (pair ? 2 : 1) * (LENGTH / 32) + reads_cap) + 64;
+    // serial reader: one 4 MiB chunk per mate; block reader: kSubmitBytes of text per batch plus the line that ends in a
+    // block but started before it; every read may waste up to one triple of padding
+    const uint64_t words_cap = 3ull * ((uint64_t) (kSubmitBytes + 2 * LENGTH) / 32 + reads_cap) + 64;
     std::vector<int> slots_on_dev((size_t) ndev, 0);
     for (int w = 0; w < n_workers; w++) slots_on_dev[(size_t) (w % ndev)]++;
     for (int d = 0; d < ndev; d++) {
@@ -170,14 +218,12 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         p.n_slots = std::max(1, slots_on_dev[(size_t) d]);
         p.max_batch_words = words_cap;
         p.max_batch_reads = reads_cap;
-        p.table_log2_slots = 22;
-        p.flags = 0;
+        p.table_log2_slots = (uint32_t) cfg.table_log2_slots;
+        p.flags = TREW_FLAG_NO_TIMING;  // ~10^4 small batches a second: every HIP call per batch counts
         trew_hip_ctx *c = nullptr;
-        if (trew_hip_init(&p, &c) != 0) {
-            fprintf(stderr, "%s\n", trew_hip_last_error(nullptr));
-            exit(EXIT_FAILURE);
-        }
-        s->ctx.push_back(c);
+        if (trew_hip_init(&p, &c) != 0) die(trew_hip_last_error(nullptr));
+        s->dev.emplace_back(new Device());
+        s->dev.back()->ctx = c;
     }
     std::vector<int> next_slot((size_t) ndev, 0);
     for (int w = 0; w < n_workers; w++) {
@@ -186,11 +232,9 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         wk.slot = next_slot[(size_t) wk.dev_index]++;
         wk.words_cap = words_cap;
         wk.reads_cap = reads_cap;
-        trew_hip_ctx *c = s->ctx[(size_t) wk.dev_index];
-        if (trew_hip_host_alloc(c, words_cap * 4, (void **) &wk.h_words) || trew_hip_host_alloc(c, reads_cap * 4, (void **) &wk.h_offsets) ||
-            trew_hip_host_alloc(c, reads_cap * 4, (void **) &wk.h_lengths))
-            hip_die(c, "pinned allocation");
-        s->workers.push_back(wk);
+        trew_hip_ctx *c = s->dev[(size_t) wk.dev_index]->ctx;
+        if (trew_hip_host_alloc(c, (words_cap + 2 * reads_cap) * 4, (void **) &wk.h_buf)) hip_die(c, "pinned allocation");
+        s->workers.push_back(std::move(wk));
     }
     return s;
 }
@@ -198,20 +242,83 @@ Scanner *scanner_create(const Config &cfg, int mode) {
 void scanner_destroy(Scanner *s) {
     if (!s) return;
     for (auto &w : s->workers) {
-        trew_hip_ctx *c = s->ctx[(size_t) w.dev_index];
-        trew_hip_host_free(c, w.h_words);
-        trew_hip_host_free(c, w.h_offsets);
-        trew_hip_host_free(c, w.h_lengths);
+        trew_hip_ctx *c = s->dev[(size_t) w.dev_index]->ctx;
+        trew_hip_host_free(c, w.h_buf);
     }
-    for (auto c : s->ctx) trew_hip_destroy(c);
+    for (auto &d : s->dev) trew_hip_destroy(d->ctx);
     delete s;
 }
 
 const RunStats &last_stats(const Scanner *s) { return s->stats; }
 
+static void add_rows_to(ResultMapData &r, const std::vector<trew_hip_row> &rows, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) {
+        const uint128_t w = ((uint128_t) rows[i].word_hi << 64) | rows[i].word_lo;
+        r.table[rows[i].table][KmerSeq{rows[i].k, w}] += rows[i].count;  // thread merge, kmer.cpp:1486-1515
+    }
+}
+
+// empties one device's tables into host memory; the caller holds the device's drain lock exclusively
+// (or no worker is running)
+static void drain_device(Scanner *s, Device *d) {
+    uint64_t n = 0;
+    if (trew_hip_collect(d->ctx, -1, nullptr, 0, &n)) hip_die(d->ctx, "trew_hip_collect");
+    std::vector<trew_hip_row> rows((size_t) std::max<uint64_t>(n, 1));
+    if (trew_hip_collect(d->ctx, -1, rows.data(), n, &n)) hip_die(d->ctx, "trew_hip_collect");
+    {
+        std::lock_guard<std::mutex> lk(s->pending_mu);
+        add_rows_to(s->pending, rows, n);
+    }
+    if (trew_hip_reset_tables(d->ctx)) hip_die(d->ctx, "trew_hip_reset_tables");
+}
+
+// true when the device table should be emptied before more rows arrive
+static bool under_pressure(trew_hip_ctx *c) {
+    uint64_t used = 0, total = 0, spilled = 0, spill_cap = 0;
+    if (trew_hip_table_pressure(c, &used, &total, &spilled, &spill_cap)) hip_die(c, "trew_hip_table_pressure");
+    return used * 2 > total || spilled > 0;
+}
+
+// hand one packed batch (already in the worker's pinned buffers) to the worker's device slot
+static void submit_packed(Scanner *s, Worker *w, uint32_t *h_words, uint32_t *h_offsets, uint32_t *h_lengths, uint64_t n_reads, uint64_t n_words) {
+    Device *d = s->dev[(size_t) w->dev_index].get();
+    trew_hip_ctx *c = d->ctx;
+    if (n_words == (uint64_t) -1) die("internal error: packed chunk exceeds the slot buffer");
+    uint32_t max_len = 0;
+    uint64_t bases = 0;
+    for (uint64_t i = 0; i < n_reads; i++) {
+        bases += h_lengths[i];
+        max_len = std::max(max_len, h_lengths[i]);
+    }
+    w->bases += bases;
+    w->reads += n_reads;
+    if (n_reads == 0) return;
+    // before every batch: has the fixed-size device table run half full (or started to spill)?  Then it is emptied
+    // into host memory before this batch adds to it.  Counts can only be lost if one batch fills what is left of the
+    // table AND the spill log (>= 64 k rows, 1 M at the default table size); trew_hip_collect reports that as an error.
+    w->submits++;
+    if (under_pressure(c)) {
+        std::unique_lock<std::shared_mutex> lk(d->drain_mu);  // waits for running submits, blocks new ones
+        if (under_pressure(c)) {                              // nobody drained in the meantime
+            drain_device(s, d);
+            s->drains++;
+        }
+    }
+    trew_hip_batch b;
+    memset(&b, 0, sizeof(b));
+    b.words = h_words;
+    b.n_words = n_words;
+    b.offsets = h_offsets;
+    b.lengths = h_lengths;
+    b.n_reads = n_reads;
+    b.max_length = (int32_t) max_len;
+    std::shared_lock<std::shared_mutex> lk(d->drain_mu);
+    if (trew_hip_submit(c, &b, w->slot)) hip_die(c, "trew_hip_submit");
+}
+
 // the consumer: buffer_task* (kmer.cpp:80-985) with the scan itself moved to the device
 static void worker_loop(Scanner *s, Worker *w, ChunkQueue *q) {
-    trew_hip_ctx *c = s->ctx[(size_t) w->dev_index];
+    trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
     for (;;) {
         Chunk *ch = q->pop();
         if (ch->sentinel) {  // loc_vector == nullptr, kmer.cpp:108-110
@@ -219,26 +326,17 @@ static void worker_loop(Scanner *s, Worker *w, ChunkQueue *q) {
             break;
         }
         if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffers are free again
-        trew_hip_batch b;
-        memset(&b, 0, sizeof(b));
-        uint64_t nw;
+        uint64_t nw, n_reads;
         if (s->mode == TREW_MODE_PAIR) {
             const uint64_t np = std::min(ch->st1.size(), ch->st2.size());  // kmer.cpp:321
-            nw = trew_pack_pairs(ch->buffer1, ch->st1.data(), ch->nd1.data(), ch->buffer2, ch->st2.data(), ch->nd2.data(), np, w->h_words,
-                                 w->words_cap, w->h_offsets, w->h_lengths);
-            b.n_reads = 2 * np;
+            n_reads = 2 * np;
+            nw = trew_pack_pairs(ch->buffer1, ch->st1.data(), ch->nd1.data(), ch->buffer2, ch->st2.data(), ch->nd2.data(), np, w->h_buf + 2 * n_reads,
+                                 w->words_cap, w->h_buf, w->h_buf + n_reads);
         } else {
-            nw = trew_pack_reads(ch->buffer1, ch->st1.data(), ch->nd1.data(), ch->st1.size(), w->h_words, w->words_cap, w->h_offsets, w->h_lengths);
-            b.n_reads = ch->st1.size();
+            n_reads = ch->st1.size();
+            nw = trew_pack_reads(ch->buffer1, ch->st1.data(), ch->nd1.data(), n_reads, w->h_buf + 2 * n_reads, w->words_cap, w->h_buf, w->h_buf + n_reads);
         }
-        if (nw == (uint64_t) -1) die("internal error: packed chunk exceeds the slot buffer");
-        for (uint64_t i = 0; i < b.n_reads; i++) w->bases += w->h_lengths[i];
-        w->reads += b.n_reads;
-        b.words = w->h_words;
-        b.n_words = nw;
-        b.offsets = w->h_offsets;
-        b.lengths = w->h_lengths;
-        if (b.n_reads && trew_hip_submit(c, &b, w->slot)) hip_die(c, "trew_hip_submit");
+        submit_packed(s, w, w->h_buf + 2 * n_reads, w->h_buf, w->h_buf + n_reads, n_reads, nw);
         free(ch->buffer1);  // the consumer owns and frees the chunk, kmer.cpp:175-176
         free(ch->buffer2);
         delete ch;
@@ -284,7 +382,9 @@ static void read_fastq_thread(FileReader &fr, ChunkQueue *q, bool long_mode, int
             q->push(ch);
             if (fr.eof()) break;
             fprintf(stderr, "File-IO Error: %s.\n", fr.error());  // kmer.cpp:1021-1022
-            exit(EXIT_FAILURE);
+            fflush(stdout);
+            fflush(stderr);
+            _exit(EXIT_FAILURE);
         }
         char *buffer_new = alloc_buffer();
         if ((num & 3) == 1) {  // inside a sequence line: carry it over (kmer.cpp:1026-1029)
@@ -329,7 +429,9 @@ static void read_pair_fastq_thread(FileReader &f1, FileReader &f2, ChunkQueue *q
                         x.bytes_read = 0;
                     } else {
                         fprintf(stderr, "File %d IO Error: %s.\n", m + 1, x.fr->error());  // kmer.cpp:1065,1080
-                        exit(EXIT_FAILURE);
+                        fflush(stdout);
+                        fflush(stderr);
+                        _exit(EXIT_FAILURE);
                     }
                 }
             } else {
@@ -354,7 +456,9 @@ static void read_pair_fastq_thread(FileReader &f1, FileReader &f2, ChunkQueue *q
         if (s[0].is_end && s[1].is_end) {
             if (s[0].num != s[1].num) {  // kmer.cpp:1112-1114
                 fprintf(stderr, "Error: Mismatched record counts between files (num1: %d, num2: %d).\n", s[0].num, s[1].num);
-                exit(EXIT_FAILURE);
+                fflush(stdout);
+                fflush(stderr);
+                _exit(EXIT_FAILURE);
             }
             ch->buffer1 = s[0].buffer;
             ch->buffer2 = s[1].buffer;
@@ -400,47 +504,157 @@ static void read_pair_fastq_thread(FileReader &f1, FileReader &f2, ChunkQueue *q
     }
 }
 
-static ResultMapData collect_tables(Scanner *s) {
-    ResultMapData r;
-    for (auto c : s->ctx) {
-        uint64_t n = 0;
-        if (trew_hip_collect(c, -1, nullptr, 0, &n)) hip_die(c, "trew_hip_collect");
-        std::vector<trew_hip_row> rows((size_t) std::max<uint64_t>(n, 1));
-        if (trew_hip_collect(c, -1, rows.data(), n, &n)) hip_die(c, "trew_hip_collect");
-        for (uint64_t i = 0; i < n; i++) {
-            const uint128_t w = ((uint128_t) rows[i].word_hi << 64) | rows[i].word_lo;
-            r.table[rows[i].table][KmerSeq{rows[i].k, w}] += rows[i].count;  // thread merge, kmer.cpp:1486-1515
-        }
-        if (trew_hip_reset_tables(c)) hip_die(c, "trew_hip_reset_tables");
+// ------------------------------------------------------------------ block-parallel reader (plain FASTQ)
+struct BlockJob {
+    BlockScan scan;
+    bool long_mode = false;
+    int slice_length = 0;
+};
+
+static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
+    trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    uint64_t acc_reads = 0, acc_words = 0;
+    size_t acc_text = 0;
+    bool buffers_free = false;  // has the slot's previous submit been waited for
+    if (w->tmp_off.size() < w->reads_cap) {
+        w->tmp_off.resize(w->reads_cap);
+        w->tmp_len.resize(w->reads_cap);
     }
+    auto close_batch = [&]() {
+        if (acc_reads == 0) return;
+        const clk::time_point t3 = clk::now();
+        uint32_t *h_off = w->h_buf + acc_words, *h_len = h_off + acc_reads;  // [words][offsets][lengths]
+        memcpy(h_off, w->tmp_off.data(), acc_reads * 4);
+        memcpy(h_len, w->tmp_len.data(), acc_reads * 4);
+        submit_packed(s, w, w->h_buf, h_off, h_len, acc_reads, acc_words);
+        acc_reads = acc_words = 0;
+        acc_text = 0;
+        buffers_free = false;
+        w->t_submit += secs(t3, clk::now());
+    };
+    for (;;) {
+        const clk::time_point t0 = clk::now();
+        if (!job->scan.claim(w->nl, w->st, w->nd)) break;
+        // the limits of the chunk reader, applied to the same lines
+        size_t keep = 0;
+        uint64_t need_words = 0;
+        for (size_t i = 0; i < w->st.size(); i++) {
+            const int64_t len = w->nd[i] - w->st[i] + 1;
+            if (job->long_mode) {
+                if (len >= LENGTH - 2) die("a read does not fit one 4 MiB chunk");
+                if (len < job->slice_length) continue;                              // kmer.cpp:1184
+            } else if (len > MAX_SEQ) {
+                die("This mode is designed for short-read sequencing. Please use 'trew long'.");  // kmer.cpp:1006-1009
+            }
+            w->st[keep] = w->st[i];
+            w->nd[keep] = w->nd[i];
+            need_words += 3ull * (((uint64_t) len + 31) / 32);
+            keep++;
+        }
+        const clk::time_point t1 = clk::now();
+        w->t_scan += secs(t0, t1);
+        // a block holds at most reads_cap sequence lines and words_cap/2 words: it always fits an empty batch
+        if (acc_reads + keep > w->reads_cap || acc_words + need_words > w->words_cap) close_batch();
+        if (!buffers_free) {
+            const clk::time_point tw = clk::now();
+            if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
+            buffers_free = true;
+            w->t_wait += secs(tw, clk::now());
+        }
+        const clk::time_point t2 = clk::now();
+        const uint64_t nw = trew_pack_reads(job->scan.base, w->st.data(), w->nd.data(), keep, w->h_buf + acc_words, w->words_cap - acc_words,
+                                            w->tmp_off.data() + acc_reads, w->tmp_len.data() + acc_reads);
+        if (nw == (uint64_t) -1) die("internal error: packed block exceeds the slot buffer");
+        for (size_t i = 0; i < keep; i++) w->tmp_off[acc_reads + i] += (uint32_t) acc_words;  // offsets count from the batch's first word
+        acc_reads += keep;
+        acc_words += nw;
+        acc_text += job->scan.block;
+        w->t_pack += secs(t2, clk::now());
+        if (acc_text >= (size_t) s->cfg.batch_mib << 20) close_batch();
+    }
+    close_batch();
+    if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");
+}
+
+// maps the file and runs the block workers; false when the file cannot be mapped (empty file, special file):
+// the caller falls back to the serial reader
+static bool run_blocks(Scanner *s, const char *name, bool long_mode, int slice_length) {
+    const int fd = open(name, O_RDONLY);
+    if (fd < 0) open_failed(name);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) {
+        close(fd);
+        return false;
+    }
+    void *m = mmap(nullptr, (size_t) st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return false;
+    (void) madvise(m, (size_t) st.st_size, MADV_SEQUENTIAL);
+    (void) madvise(m, (size_t) st.st_size, MADV_WILLNEED);
+    BlockJob job;
+    job.scan.init((const char *) m, (size_t) st.st_size, (size_t) LENGTH);
+    job.scan.populate = true;
+    job.long_mode = long_mode;
+    job.slice_length = slice_length;
+    std::vector<std::thread> th;
+    for (auto &w : s->workers) th.emplace_back(block_worker_loop, s, &w, &job);
+    for (auto &t : th) t.join();
+    munmap(m, (size_t) st.st_size);
+    return true;
+}
+
+// thread merge of process_output (kmer.cpp:1486-1515): what was drained during the file + what the devices
+// still hold.  With several devices the tables are first reduced on the GPUs (trew_hip_merge, one peer copy
+// per device) and only the merged rows cross PCIe.
+static ResultMapData collect_tables(Scanner *s) {
+    for (size_t d = 1; d < s->dev.size(); d++) {
+        if (trew_hip_merge(s->dev[0]->ctx, s->dev[d]->ctx)) hip_die(s->dev[0]->ctx, "trew_hip_merge");
+        if (trew_hip_reset_tables(s->dev[d]->ctx)) hip_die(s->dev[d]->ctx, "trew_hip_reset_tables");
+    }
+    drain_device(s, s->dev[0].get());
+    ResultMapData r;
+    std::lock_guard<std::mutex> lk(s->pending_mu);
+    std::swap(r, s->pending);
     return r;
 }
 
 static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name1, const char *name2, bool gz1, bool gz2) {
     const auto t0 = std::chrono::steady_clock::now();
-    size_t qcap = cfg.QUEUE_SIZE >= 4 ? (size_t) (cfg.QUEUE_SIZE / 4) : 256;  // kmer.cpp:1274-1276; "unlimited" is capped at 1 GiB
-    ChunkQueue q(qcap);
     for (auto &w : s->workers) {
         w.reads = 0;
         w.bases = 0;
+        w.t_scan = w.t_wait = w.t_pack = w.t_submit = 0;
     }
-    std::vector<std::thread> th;
-    for (auto &w : s->workers) th.emplace_back(worker_loop, s, &w, &q);
-    FileReader f1 = open_reader(name1, gz1);
-    if (s->mode == TREW_MODE_PAIR) {
-        FileReader f2 = open_reader(name2, gz2);
-        read_pair_fastq_thread(f1, f2, &q);
-        f2.close();
-    } else {
-        read_fastq_thread(f1, &q, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
+    const uint64_t drains0 = s->drains;
+    bool done = false;
+    const char *how = "serial reader";
+    if (s->mode != TREW_MODE_PAIR && !gz1 && !cfg.serial_reader) {
+        done = run_blocks(s, name1, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
+        if (done) how = "block-parallel reader";
     }
-    f1.close();
-    for (size_t i = 0; i < s->workers.size(); i++) {  // sentinels, kmer.cpp:1304-1310
-        Chunk *c = new Chunk();
-        c->sentinel = true;
-        q.push(c);
+    if (!done) {
+        size_t qcap = cfg.QUEUE_SIZE >= 4 ? (size_t) (cfg.QUEUE_SIZE / 4) : 256;  // kmer.cpp:1274-1276; "unlimited" is capped at 1 GiB
+        ChunkQueue q(qcap);
+        std::vector<std::thread> th;
+        for (auto &w : s->workers) th.emplace_back(worker_loop, s, &w, &q);
+        FileReader f1 = open_reader(name1, gz1);
+        if (s->mode == TREW_MODE_PAIR) {
+            FileReader f2 = open_reader(name2, gz2);
+            read_pair_fastq_thread(f1, f2, &q);
+            f2.close();
+        } else {
+            read_fastq_thread(f1, &q, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
+        }
+        f1.close();
+        for (size_t i = 0; i < s->workers.size(); i++) {  // sentinels, kmer.cpp:1304-1310
+            Chunk *c = new Chunk();
+            c->sentinel = true;
+            q.push(c);
+        }
+        for (auto &t : th) t.join();
     }
-    for (auto &t : th) t.join();
     ResultMapData r = collect_tables(s);
     s->stats = RunStats();
     for (auto &w : s->workers) {
@@ -449,9 +663,16 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
     }
     s->stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (cfg.stats)
-        fprintf(stderr, "[trew] %s: %llu reads, %llu bases, %.3f s, %.3f Gbases/s end-to-end (decode + pack + scan)\n", name1,
-                (unsigned long long) s->stats.reads, (unsigned long long) s->stats.bases, s->stats.seconds,
-                s->stats.bases / s->stats.seconds / 1e9);
+        fprintf(stderr, "[trew] %s: %llu reads, %llu bases, %.3f s, %.3f Gbases/s end-to-end (decode + pack + scan; %s, %d worker(s), %llu table drain(s))\n",
+                name1, (unsigned long long) s->stats.reads, (unsigned long long) s->stats.bases, s->stats.seconds,
+                s->stats.bases / s->stats.seconds / 1e9, how, (int) s->workers.size(), (unsigned long long) (s->drains - drains0));
+    if (cfg.stats && done) {
+        double a = 0, b = 0, c = 0, d = 0;
+        for (auto &w : s->workers) a += w.t_scan, b += w.t_wait, c += w.t_pack, d += w.t_submit;
+        const double n = (double) s->workers.size();
+        fprintf(stderr, "[trew]   per worker (mean seconds): newline scan + line chain %.3f, wait for the slot %.3f, pack %.3f, submit %.3f\n", a / n, b / n,
+                c / n, d / n);
+    }
     return process_output(name1, r, cfg.MIN_MER, stdout);  // pair mode prints file 1 only (kmer.cpp:1409)
 }
 

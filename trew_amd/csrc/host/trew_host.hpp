@@ -35,6 +35,9 @@ struct Config {
     int TABLE_MAX_MER = 12;  // accepted for CLI compatibility; the device path has no tables
     std::vector<int> devices = {0};
     bool stats = false;
+    int table_log2_slots = 24;   // device count table: 2^24 slots (256 MiB); emptied into host memory whenever half full
+    bool serial_reader = false;  // --serial_reader: plain FASTQ through the reference-shaped single reader as well
+    int batch_mib = 32;          // --batch_mib: text per device batch of the block-parallel reader (1..32 MiB)
 };
 
 // KmerSeq (kmer.h:77) with a total order so that output is deterministic

@@ -2,7 +2,8 @@
 //
 // Same sub-commands, positional arguments, options, limits and messages as the reference CLI
 // (trew.cpp:22-478): stdout carries the CSV sections, stderr errors/usage, exit code 1 on error.
-// Additions (stderr only, stdout stays CSV-identical): --devices LIST, --stats.
+// Additions (stderr only, stdout stays CSV-identical): --devices LIST, --stats, --table_log2_slots N,
+// --serial_reader, --batch_mib N.
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -20,13 +21,14 @@ static void usage(const char *mode) {
         fprintf(stderr,
                 "Usage: long [--help] [--version] [--thread THREAD] [--table_max_mer TABLE_MAX_MER] [--low_baseline LOW_BASELINE]\n"
                 "            [--high_baseline HIGH_BASELINE] [--slice_length SLICE_LENGTH] [--queue_size QUEUE_SIZE]\n"
-                "            [--devices LIST] [--stats] MIN_MER MAX_MER LONG_FASTQ...\n\n"
+                "            [--devices LIST] [--stats] [--table_log2_slots N] [--serial_reader] [--batch_mib N] MIN_MER MAX_MER LONG_FASTQ...\n\n"
                 "Estimate TRM from long-read sequencing data.\n");
     } else if (mode && !strcmp(mode, "short")) {
         fprintf(stderr,
                 "Usage: short [--help] [--version] [--thread THREAD] [--paired_end] [--fq1 FASTQ_FRONT...] [--fq2 FASTQ_REVERSE...]\n"
                 "             [--table_max_mer TABLE_MAX_MER] [--low_baseline LOW_BASELINE] [--high_baseline HIGH_BASELINE]\n"
-                "             [--queue_size QUEUE_SIZE] [--devices LIST] [--stats] MIN_MER MAX_MER [SHORT_FASTQ]...\n\n"
+                "             [--queue_size QUEUE_SIZE] [--devices LIST] [--stats] [--table_log2_slots N] [--serial_reader]\n"
+                "             [--batch_mib N] MIN_MER MAX_MER [SHORT_FASTQ]...\n\n"
                 "Estimate TRM from short-read sequencing data.\n");
     } else {
         fprintf(stderr, "Usage: trew [--help] [--version] {long,short}\n\nSubcommands:\n  long          Estimate TRM from long-read sequencing data.\n"
@@ -138,6 +140,15 @@ int main(int argc, char **argv) {
         } else if (a == "--stats") {
             multi = nullptr;
             cfg.stats = true;
+        } else if (a == "--serial_reader") {
+            multi = nullptr;
+            cfg.serial_reader = true;
+        } else if (a == "--batch_mib") {
+            multi = nullptr;
+            ok = parse_int(need("--batch_mib"), &cfg.batch_mib) && cfg.batch_mib >= 1 && cfg.batch_mib <= 32;
+        } else if (a == "--table_log2_slots") {
+            multi = nullptr;
+            ok = parse_int(need("--table_log2_slots"), &cfg.table_log2_slots);
         } else if (a == "--devices") {
             multi = nullptr;
             std::string list = need("--devices");
@@ -188,6 +199,8 @@ int main(int argc, char **argv) {
     if (!(0 < cfg.LOW_BASELINE && cfg.LOW_BASELINE <= 1) || !(0 < cfg.HIGH_BASELINE && cfg.HIGH_BASELINE <= 1)) return bad("Baseline must be in range 0 to 1.");
     if (cfg.LOW_BASELINE > cfg.HIGH_BASELINE) return bad("Low baseline must be smaller than high baseline.");
     if (cfg.NUM_THREAD < 2) return bad("You must use at least two threads.");
+    if (cfg.table_log2_slots < 12 || cfg.table_log2_slots > 30) return bad("table_log2_slots must be in range 12 to 30.");
+    if (cfg.NUM_THREAD - 1 > 16 * (int) cfg.devices.size()) cfg.NUM_THREAD = 16 * (int) cfg.devices.size() + 1;  // 16 batch slots per device
 
     std::vector<std::string> fastq_path_list;
     if (!IS_SHORT) {

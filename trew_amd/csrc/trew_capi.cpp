@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -23,9 +25,8 @@ namespace {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    u32 *d_words = nullptr;
-    u32 *d_offsets = nullptr;
-    u32 *d_lengths = nullptr;
+    u32 *d_buf = nullptr;  // one allocation: [offsets max_batch_reads][lengths max_batch_reads][words max_batch_words + slack]
+    u32 *d_words = nullptr, *d_offsets = nullptr, *d_lengths = nullptr;  // views into d_buf
     u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
@@ -33,13 +34,22 @@ struct Slot {
     // on the slot's stream without a wait in between, each keeps its own timestamps
     static constexpr int kRing = 128;
     hipEvent_t ev[kRing][3] = {};
+    u64 n_launches = 0;  // submits that launched kernels: picks the counter block
     u64 n_submits = 0;   // submits since init
     u64 n_reported = 0;  // submits already averaged by trew_hip_last_timing
     u64 n_units = 0;
 };
 
 thread_local std::string g_init_error;  // trew_hip_init failures before a context exists (read back on the same thread)
-constexpr size_t kWlCountBytes = (32 + 8 * 32) * 4;  // [0] worklist size, then 8 queue heads on separate 128-B lines
+// Last error of the calling thread.  Several host threads share one context (one slot each); an error string
+// inside the context would be written and read concurrently, so the text lives with the thread that got the
+// failing status -- the only one that reads it back.
+thread_local std::string g_thread_error;
+// One counter block: [0] worklist size, then 8 queue heads on separate 128-B lines.  A slot owns TWO blocks and
+// alternates between them; the exact kernel of one submit clears the block of the next (see exact_kernel), so a
+// submit needs no memset call of its own.  Both are cleared once at init.
+constexpr size_t kWlCountWords = 32 + 8 * 32;
+constexpr size_t kWlCountBytes = kWlCountWords * 4;
 
 }  // namespace
 
@@ -50,25 +60,29 @@ struct trew_hip_ctx {
     DevWide wide;  // host copy of *table.wide
     u64 table_slots = 0;
     std::vector<Slot> slots;
-    std::string err;
     int n_cu = 256;
     // persistent scratch of trew_hip_collect (device-side compaction)
     unsigned long long *d_collect_n = nullptr;
     trew_hip_row *d_collect_rows = nullptr;
     u64 collect_cap = 0;
+    // persistent scratch of trew_hip_add_rows / trew_hip_merge (grow-only)
+    trew_hip_row *d_add_rows = nullptr;
+    u64 add_cap = 0;
+    std::mutex table_mu;  // collect / reset / add_rows / merge are whole-table operations: one at a time
 };
 
 #define HIPCHK(ctx, expr)                                                                         \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            (void) (ctx);                                                                         \
+            g_thread_error = std::string(#expr) + ": " + hipGetErrorString(e_);                   \
             return (int) e_ ? (int) e_ : -1;                                                      \
         }                                                                                         \
     } while (0)
 
-static int fail(trew_hip_ctx *ctx, const std::string &msg) {
-    ctx->err = msg;
+static int fail(trew_hip_ctx *, const std::string &msg) {
+    g_thread_error = msg;
     return -1;
 }
 
@@ -84,7 +98,7 @@ extern "C" int trew_hip_host_alloc(trew_hip_ctx *ctx, uint64_t bytes, void **h_p
     hipError_t e = hipSetDevice(ctx->p.device);
     if (e == hipSuccess) e = hipHostMalloc(h_ptr, bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
-        ctx->err = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        g_thread_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
         return (int) e;
     }
     return 0;
@@ -94,14 +108,14 @@ extern "C" int trew_hip_host_free(trew_hip_ctx *ctx, void *h_ptr) {
     if (!ctx) return -1;
     hipError_t e = hipHostFree(h_ptr);
     if (e != hipSuccess) {
-        ctx->err = std::string("hipHostFree: ") + hipGetErrorString(e);
+        g_thread_error = std::string("hipHostFree: ") + hipGetErrorString(e);
         return (int) e;
     }
     return 0;
 }
 
 extern "C" const char *trew_hip_last_error(const trew_hip_ctx *ctx) {
-    return ctx ? ctx->err.c_str() : g_init_error.c_str();
+    return ctx ? g_thread_error.c_str() : g_init_error.c_str();
 }
 
 static float conservative_lowf(double low) {
@@ -166,10 +180,10 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     ctx->table.log2_part_slots = p.table_log2_slots - kTablePartBits;
     if ((e = hipMalloc((void **) &ctx->table.keys, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table keys)", e);
     if ((e = hipMalloc((void **) &ctx->table.counts, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table counts)", e);
-    if ((e = hipMalloc((void **) &ctx->table.overflow, 4)) != hipSuccess) return bail("hipMalloc(overflow)", e);
+    if ((e = hipMalloc((void **) &ctx->table.overflow, kDiagWords * 4)) != hipSuccess) return bail("hipMalloc(overflow)", e);
     if ((e = hipMemset(ctx->table.keys, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
     if ((e = hipMemset(ctx->table.counts, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->table.overflow, 0, 4)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemset(ctx->table.overflow, 0, kDiagWords * 4)) != hipSuccess) return bail("hipMemset", e);
     // wide entries (k > 32) are rare: a quarter of the slots
     ctx->wide.wide_log2_slots = std::max<u32>(10u, p.table_log2_slots - 2u);
     {
@@ -193,14 +207,18 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     ctx->slots.resize((size_t) p.n_slots);
     for (auto &s : ctx->slots) {
         if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-        if (p.max_batch_words) {
-            // +8 words of slack: load_planes may prefetch one triple past a read's last one
-            if ((e = hipMalloc((void **) &s.d_words, (p.max_batch_words + 8) * 4)) != hipSuccess) return bail("hipMalloc(words)", e);
+        {
+            // +8 words of slack: the exact kernel fetches whole 64-word heads of a read
+            const size_t words = 2 * (size_t) p.max_batch_reads + (size_t) p.max_batch_words + 8;
+            if ((e = hipMalloc((void **) &s.d_buf, words * 4)) != hipSuccess) return bail("hipMalloc(batch buffer)", e);
+            if ((e = hipMemset(s.d_buf, 0, words * 4)) != hipSuccess) return bail("hipMemset", e);
+            s.d_offsets = s.d_buf;
+            s.d_lengths = s.d_buf + p.max_batch_reads;
+            s.d_words = s.d_buf + 2 * (size_t) p.max_batch_reads;
         }
-        if ((e = hipMalloc((void **) &s.d_offsets, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(offsets)", e);
-        if ((e = hipMalloc((void **) &s.d_lengths, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc(lengths)", e);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
-        if ((e = hipMalloc((void **) &s.d_wl_count, kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
+        if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
+        if ((e = hipMemset(s.d_wl_count, 0, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMemset", e);
         if (p.mode == TREW_MODE_SEGMENT) {
             if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
@@ -222,9 +240,7 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     (void) hipSetDevice(ctx->p.device);
     for (auto &s : ctx->slots) {
         if (s.stream) (void) hipStreamSynchronize(s.stream);
-        if (s.d_words) (void) hipFree(s.d_words);
-        if (s.d_offsets) (void) hipFree(s.d_offsets);
-        if (s.d_lengths) (void) hipFree(s.d_lengths);
+        if (s.d_buf) (void) hipFree(s.d_buf);
         if (s.d_wl) (void) hipFree(s.d_wl);
         if (s.d_wl_count) (void) hipFree(s.d_wl_count);
         if (s.res.k_high) (void) hipFree(s.res.k_high);
@@ -250,6 +266,7 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
+    if (ctx->d_add_rows) (void) hipFree(ctx->d_add_rows);
     delete ctx;
 }
 
@@ -272,10 +289,30 @@ static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_s
         return m;
     };
     if (b->lengths && !b->on_device) {
+        // Longest segment over the batch.  It only sizes the kernels (mask words, LDS), so a value that is never
+        // too small is what matters; the closed forms below equal unit_seg() except that a whole-read segment is
+        // assumed whenever the read is shorter than 4*MAX_MER (get_segment also wants kmin <= kmax).  One pass of
+        // a few instructions per read instead of three get_segment() calls: the CLI submits ~10^4 batches a second.
+        const u32 two_min = (u32) (2 * MINM), four_min = (u32) (4 * MINM), four_max = (u32) (4 * MAXM);
         if (mode == TREW_MODE_PAIR) {
             for (u64 i = 0; i + 1 < b->n_reads; i += 2) {
-                maxlen = std::max(maxlen, std::max(b->lengths[i], b->lengths[i + 1]));
-                ms = std::max(ms, unit_seg(b->lengths[i], b->lengths[i + 1]));
+                const u32 a = b->lengths[i], c = b->lengths[i + 1], hi = std::max(a, c), lo = std::min(a, c);
+                maxlen = std::max(maxlen, hi);
+                if (lo >= four_min) ms = std::max(ms, (hi + 1) / 2);
+                if (lo >= two_min && lo < four_max) ms = std::max(ms, hi);
+            }
+        } else if (mode == TREW_MODE_SHORT) {
+            for (u64 i = 0; i < b->n_reads; i++) {
+                const u32 n = b->lengths[i];
+                maxlen = std::max(maxlen, n);
+                if (n >= two_min && n < four_max) ms = std::max(ms, n);
+            }
+            if (maxlen >= four_min) ms = std::max(ms, (maxlen + 1) / 2);
+        } else if (mode == TREW_MODE_LONG) {
+            for (u64 i = 0; i < b->n_reads; i++) {
+                const u32 n = b->lengths[i];
+                maxlen = std::max(maxlen, n);
+                if ((int) n >= SL) ms = std::max(ms, (u32) SL + n % (u32) SL);  // the middle slice carries the remainder (kmer.cpp:790-798)
             }
         } else {
             for (u64 i = 0; i < b->n_reads; i++) {
@@ -322,8 +359,23 @@ static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevB
         db->lengths = b->lengths;
     } else {
         if (b->n_words > ctx->p.max_batch_words) return fail(ctx, "batch has more words than max_batch_words");
+        // The caller laid the three arrays out back to back in one buffer (see trew_hip.h): ONE copy.  A host that
+        // submits thousands of batches a second is bound by HIP API calls, not by bytes.
+        if (b->offsets && b->lengths == b->offsets + b->n_reads && b->words == b->lengths + b->n_reads) {  // [offsets][lengths][words]
+            HIPCHK(ctx, hipMemcpyAsync(s.d_buf, b->offsets, (2 * b->n_reads + b->n_words) * 4, hipMemcpyHostToDevice, s.stream));
+            db->offsets = s.d_buf;
+            db->lengths = s.d_buf + b->n_reads;
+            db->words = s.d_buf + 2 * b->n_reads;
+            return 0;
+        }
+        if (b->offsets && b->offsets == b->words + b->n_words && b->lengths == b->offsets + b->n_reads) {  // [words][offsets][lengths]
+            HIPCHK(ctx, hipMemcpyAsync(s.d_buf, b->words, (2 * b->n_reads + b->n_words) * 4, hipMemcpyHostToDevice, s.stream));
+            db->words = s.d_buf;
+            db->offsets = s.d_buf + b->n_words;
+            db->lengths = s.d_buf + b->n_words + b->n_reads;
+            return 0;
+        }
         HIPCHK(ctx, hipMemcpyAsync(s.d_words, b->words, b->n_words * 4, hipMemcpyHostToDevice, s.stream));
-        HIPCHK(ctx, hipMemsetAsync(s.d_words + b->n_words, 0, 8 * 4, s.stream));
         db->words = s.d_words;
         db->offsets = nullptr;
         db->lengths = nullptr;
@@ -348,7 +400,6 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
     s.n_units = db.n_units;
     if (db.n_units == 0) return 0;
-    HIPCHK(ctx, hipMemsetAsync(s.d_wl_count, 0, kWlCountBytes, s.stream));
     if (ctx->p.mode == TREW_MODE_SEGMENT) {
         HIPCHK(ctx, hipMemsetAsync(s.res.k_high, 0, db.n_reads * 4, s.stream));
         HIPCHK(ctx, hipMemsetAsync(s.res.k_low, 0, db.n_reads * 4, s.stream));
@@ -358,10 +409,14 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
         HIPCHK(ctx, hipMemsetAsync(s.res.seq_low_hi, 0, db.n_reads * 8, s.stream));
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
+    u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;        // clean: cleared by the previous launch
+    u32 *const wl_count_next = s.d_wl_count + ((s.n_launches + 1) & 1) * kWlCountWords;  // this launch clears it
+    s.n_launches++;
+    const bool timed = !(ctx->p.flags & TREW_FLAG_NO_TIMING);
     hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
-    HIPCHK(ctx, hipEventRecord(ev[0], s.stream));
-    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, wl_cap, nullptr, 0));
-    HIPCHK(ctx, hipEventRecord(ev[1], s.stream));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[0], s.stream));
+    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, wl_cap, nullptr, 0, ctx->table.overflow));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[1], s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
@@ -369,8 +424,8 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
     DevTable tbl = ctx->table;
     if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
-    HIPCHK(ctx, launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, s.d_wl_count, wl_cap, s.res, cap, rawwords, max_seg));
-    HIPCHK(ctx, hipEventRecord(ev[2], s.stream));
+    HIPCHK(ctx, launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
+    if (timed) HIPCHK(ctx, hipEventRecord(ev[2], s.stream));
     s.n_submits++;
     return 0;
 }
@@ -389,50 +444,81 @@ static int sync_all(trew_hip_ctx *ctx) {
     return 0;
 }
 
-extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows, uint64_t cap, uint64_t *n_rows) {
-    if (!ctx || !n_rows) return -1;
-    if (table < -1 || table >= TREW_NUM_TABLES) return fail(ctx, "table out of range");
-    if (int rc = sync_all(ctx)) return rc;
-    u32 ovf = 0;
-    HIPCHK(ctx, hipMemcpy(&ovf, ctx->table.overflow, 4, hipMemcpyDeviceToHost));
-    if (ovf) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
+// reads the device counters; a non-zero "cannot happen" counter is an error, never a silent loss
+static int check_diag(trew_hip_ctx *ctx, u32 (&diag)[kDiagWords]) {
+    HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
+    if (diag[kDiagOverflow]) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
+    if (diag[kDiagWorklistDrop]) return fail(ctx, "internal error: the prefilter worklist overflowed (survivors were dropped)");
+    if (diag[kDiagIntentDrop]) return fail(ctx, "internal error: a pair logged more than 32 deferred emissions (some were dropped)");
+    if (diag[kDiagBadRow]) return fail(ctx, "trew_hip_add_rows_device: row out of range");
+    return 0;
+}
+
+static int ensure_rows(trew_hip_ctx *ctx, trew_hip_row **buf, u64 *cap, u64 want) {
+    if (want <= *cap) return 0;
+    if (*buf) (void) hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    want = std::max<u64>(want + want / 4, 1ull << 16);
+    HIPCHK(ctx, hipMalloc((void **) buf, want * sizeof(trew_hip_row)));
+    *cap = want;
+    return 0;
+}
+
+// Compacts the occupied slots of `table` (-1: all) followed by the spill log into d_rows (device memory, capacity
+// cap rows) and reports the number of rows there are.  Rows may repeat a key (spilled rows, wide duplicates).
+// Caller holds table_mu and has synchronised the slots.
+static int compact_to(trew_hip_ctx *ctx, int table, trew_hip_row *d_rows, u64 cap, u64 *n_rows) {
+    u32 diag[kDiagWords];
+    if (int rc = check_diag(ctx, diag)) return rc;
     u32 n_spill = 0;
     HIPCHK(ctx, hipMemcpy(&n_spill, ctx->wide.spill_n, 4, hipMemcpyDeviceToHost));
     n_spill = std::min(n_spill, ctx->wide.spill_cap);
-    // compact on the device, copy only the occupied rows (scratch buffers persist across calls)
-    const u64 dcap = rows ? cap : 0;
     if (!ctx->d_collect_n) HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_n, 8));
-    if (dcap > ctx->collect_cap) {
-        if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
-        ctx->d_collect_rows = nullptr;
-        ctx->collect_cap = 0;
-        const u64 want = std::max<u64>(dcap, 1ull << 16);
-        HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_rows, want * sizeof(trew_hip_row)));
-        ctx->collect_cap = want;
-    }
     hipStream_t st = ctx->slots[0].stream;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_collect_n, 0, 8, st));
-    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, ctx->wide.wide_log2_slots, table, ctx->d_collect_rows, dcap, ctx->d_collect_n));
+    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, ctx->wide.wide_log2_slots, table, d_rows, d_rows ? cap : 0, ctx->d_collect_n));
     unsigned long long n = 0;
     HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_collect_n, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    if (dcap && n) HIPCHK(ctx, hipMemcpy(rows, ctx->d_collect_rows, std::min<u64>(n, dcap) * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
     if (n_spill) {
-        // rows that found their partition full: append them; duplicates are merged below
-        std::vector<trew_hip_row> sp(n_spill);
-        HIPCHK(ctx, hipMemcpy(sp.data(), ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
-        for (const auto &r : sp) {
-            if (table >= 0 && r.table != table) continue;
-            if (dcap && n < dcap) rows[n] = r;
-            n++;
+        if (table < 0) {  // the log is device-resident: append it as it is
+            if (d_rows && n + n_spill <= cap)
+                HIPCHK(ctx, hipMemcpy(d_rows + n, ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToDevice));
+            n += n_spill;
+        } else {  // one table only: select on the host (rare path)
+            std::vector<trew_hip_row> sp(n_spill);
+            HIPCHK(ctx, hipMemcpy(sp.data(), ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
+            for (const auto &r : sp) {
+                if (r.table != table) continue;
+                if (d_rows && n < cap) HIPCHK(ctx, hipMemcpy(d_rows + n, &r, sizeof(r), hipMemcpyHostToDevice));
+                n++;
+            }
         }
     }
+    *n_rows = n;
+    return 0;
+}
+
+extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows, uint64_t cap, uint64_t *n_rows) {
+    if (!ctx || !n_rows) return -1;
+    if (table < -1 || table >= TREW_NUM_TABLES) return fail(ctx, "table out of range");
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    // compact on the device, copy only the occupied rows (scratch buffers persist across calls)
+    const u64 dcap = rows ? cap : 0;
+    if (int rc = ensure_rows(ctx, &ctx->d_collect_rows, &ctx->collect_cap, dcap)) return rc;
+    u64 n = 0;
+    if (int rc = compact_to(ctx, table, dcap ? ctx->d_collect_rows : nullptr, dcap, &n)) return rc;
     if (dcap && n && n <= dcap) {
+        HIPCHK(ctx, hipMemcpy(rows, ctx->d_collect_rows, n * sizeof(trew_hip_row), hipMemcpyDeviceToHost));
         // the wide-entry protocol may leave one key in two slots (see table_add_wide), spilled rows repeat
         // keys: counts are sums, merge them
-        bool any_wide = n_spill != 0;
-        for (u64 i = 0; i < n && !any_wide; i++) any_wide = rows[i].k > 32;
-        if (any_wide) {
+        u32 n_spill = 0;
+        HIPCHK(ctx, hipMemcpy(&n_spill, ctx->wide.spill_n, 4, hipMemcpyDeviceToHost));
+        bool any_dup = n_spill != 0;
+        for (u64 i = 0; i < n && !any_dup; i++) any_dup = rows[i].k > 32;
+        if (any_dup) {
             std::sort(rows, rows + n, [](const trew_hip_row &a, const trew_hip_row &b) {
                 if (a.table != b.table) return a.table < b.table;
                 if (a.k != b.k) return a.k < b.k;
@@ -454,12 +540,18 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
     return 0;
 }
 
-extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
-    if (!ctx) return -1;
+extern "C" int trew_hip_collect_device(trew_hip_ctx *ctx, trew_hip_row *d_rows, uint64_t cap, uint64_t *n_rows) {
+    if (!ctx || !n_rows) return -1;
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
     if (int rc = sync_all(ctx)) return rc;
+    HIPCHK(ctx, hipDeviceSynchronize());  // the caller's buffer may still be in use on a stream of its own (torch)
+    return compact_to(ctx, -1, d_rows, d_rows ? cap : 0, n_rows);
+}
+
+static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->table.keys, 0, ctx->table_slots * 8));
     HIPCHK(ctx, hipMemset(ctx->table.counts, 0, ctx->table_slots * 8));
-    HIPCHK(ctx, hipMemset(ctx->table.overflow, 0, 4));
+    HIPCHK(ctx, hipMemset(ctx->table.overflow, 0, kDiagWords * 4));
     const size_t wb = (size_t) 8 << ctx->wide.wide_log2_slots;
     HIPCHK(ctx, hipMemset(ctx->wide.wtag, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.wlo, 0, wb));
@@ -469,21 +561,81 @@ extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
     return 0;
 }
 
+extern "C" int trew_hip_reset_tables(trew_hip_ctx *ctx) {
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    return reset_locked(ctx);
+}
+
+extern "C" int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *total_slots, uint64_t *spilled_rows,
+                                       uint64_t *spill_capacity) {
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    u32 diag[kDiagWords];
+    u32 n_spill = 0;
+    // plain blocking copies: a snapshot of monotonic counters, the slot streams are not waited for
+    HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(&n_spill, ctx->wide.spill_n, 4, hipMemcpyDeviceToHost));
+    // the narrow and the wide table fill independently: report the fuller one, scaled to the narrow table's size
+    const u64 wide_slots = 1ull << ctx->wide.wide_log2_slots;
+    const u64 wide_scaled = (u64) ((double) diag[kDiagInsertedWide] / (double) wide_slots * (double) ctx->table_slots);
+    if (used_slots) *used_slots = std::max<u64>(diag[kDiagInserted], wide_scaled);
+    if (total_slots) *total_slots = ctx->table_slots;
+    if (spilled_rows) *spilled_rows = diag[kDiagOverflow] ? (u64) ctx->wide.spill_cap + 1 : n_spill;
+    if (spill_capacity) *spill_capacity = ctx->wide.spill_cap;
+    return 0;
+}
+
+static int add_device_rows_locked(trew_hip_ctx *ctx, const trew_hip_row *d_rows, u64 n_rows) {
+    HIPCHK(ctx, launch_add_rows(ctx->slots[0].stream, ctx->table, d_rows, n_rows));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->slots[0].stream));
+    u32 diag[kDiagWords];
+    return check_diag(ctx, diag);
+}
+
 extern "C" int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_rows) {
     if (!ctx) return -1;
     if (n_rows == 0) return 0;
-    if (int rc = sync_all(ctx)) return rc;
     for (u64 i = 0; i < n_rows; i++)
         if (rows[i].k < 1 || rows[i].k > 64 || rows[i].table < 0 || rows[i].table >= TREW_NUM_TABLES || (rows[i].k <= 32 && rows[i].word_hi))
             return fail(ctx, "trew_hip_add_rows: row out of range");
-    trew_hip_row *d = nullptr;
-    HIPCHK(ctx, hipMalloc((void **) &d, n_rows * sizeof(trew_hip_row)));
-    hipError_t e = hipMemcpy(d, rows, n_rows * sizeof(trew_hip_row), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = launch_add_rows(ctx->slots[0].stream, ctx->table, d, n_rows);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->slots[0].stream);
-    (void) hipFree(d);
-    HIPCHK(ctx, e);
-    return 0;
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    if (int rc = ensure_rows(ctx, &ctx->d_add_rows, &ctx->add_cap, n_rows)) return rc;  // persistent scratch: no malloc/free per call
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_add_rows, rows, n_rows * sizeof(trew_hip_row), hipMemcpyHostToDevice, ctx->slots[0].stream));
+    return add_device_rows_locked(ctx, ctx->d_add_rows, n_rows);
+}
+
+extern "C" int trew_hip_add_rows_device(trew_hip_ctx *ctx, const trew_hip_row *d_rows, uint64_t n_rows) {
+    if (!ctx) return -1;
+    if (n_rows == 0) return 0;
+    if (!d_rows) return fail(ctx, "trew_hip_add_rows_device: null rows");
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    HIPCHK(ctx, hipDeviceSynchronize());  // the rows may have been produced on a stream of the caller's (an RCCL all_gather)
+    return add_device_rows_locked(ctx, d_rows, n_rows);
+}
+
+extern "C" int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src) {
+    if (!dst || !src) return -1;
+    if (dst == src) return fail(dst, "trew_hip_merge: source and destination are the same context");
+    // lock order by address: two threads merging in opposite directions cannot deadlock
+    std::mutex *m1 = &dst->table_mu, *m2 = &src->table_mu;
+    if (m2 < m1) std::swap(m1, m2);
+    std::lock_guard<std::mutex> l1(*m1), l2(*m2);
+    if (int rc = sync_all(src)) return rc;
+    u64 n = 0;
+    if (int rc = compact_to(src, -1, nullptr, 0, &n)) return rc;  // size first
+    if (n == 0) return 0;
+    if (int rc = ensure_rows(src, &src->d_collect_rows, &src->collect_cap, n)) return rc;
+    if (int rc = compact_to(src, -1, src->d_collect_rows, src->collect_cap, &n)) return rc;
+    if (int rc = sync_all(dst)) return rc;
+    if (int rc = ensure_rows(dst, &dst->d_add_rows, &dst->add_cap, n)) return rc;
+    // device to device: over xGMI when the contexts sit on two GPUs, a plain copy when they share one
+    HIPCHK(dst, hipMemcpyPeer(dst->d_add_rows, dst->p.device, src->d_collect_rows, src->p.device, n * sizeof(trew_hip_row)));
+    HIPCHK(dst, hipSetDevice(dst->p.device));
+    return add_device_rows_locked(dst, dst->d_add_rows, n);
 }
 
 extern "C" int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,
@@ -517,10 +669,12 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     u64 *d = nullptr;
     const u64 bytes = db.n_units * (u64) slots_per_read * 8ull;
     HIPCHK(ctx, hipMalloc((void **) &d, bytes));
+    u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
-    if (e == hipSuccess) e = hipMemsetAsync(s.d_wl_count, 0, kWlCountBytes, s.stream);
     if (e == hipSuccess)
-        e = launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, s.d_wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read);
+        e = launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read,
+                          ctx->table.overflow);
+    if (e == hipSuccess) e = hipMemsetAsync(wl_count, 0, kWlCountBytes, s.stream);  // no exact kernel follows: leave the block clean
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
     if (e == hipSuccess) e = hipMemcpy(cand, d, bytes, hipMemcpyDeviceToHost);
     (void) hipFree(d);
@@ -531,6 +685,7 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
 extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filter, float *ms_exact, uint64_t *n_flagged) {
     if (!ctx) return -1;
     if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    if (ctx->p.flags & TREW_FLAG_NO_TIMING) return fail(ctx, "the context was created with TREW_FLAG_NO_TIMING");
     if (int rc = trew_hip_wait(ctx, slot)) return rc;
     Slot &s = ctx->slots[(size_t) slot];
     // mean over the submits since the previous call (at most the last kRing of them)
@@ -552,7 +707,7 @@ extern "C" int trew_hip_last_timing(trew_hip_ctx *ctx, int slot, float *ms_filte
     if (ms_exact) *ms_exact = (float) (se / cnt);
     if (n_flagged) {  // optional: costs one blocking 4-byte copy
         u32 c = 0;
-        HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count, 4, hipMemcpyDeviceToHost));
+        if (s.n_launches) HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count + ((s.n_launches - 1) & 1) * kWlCountWords, 4, hipMemcpyDeviceToHost));
         *n_flagged = c;
     }
     return 0;
@@ -589,6 +744,19 @@ __attribute__((target("avx2"))) inline void pack32_avx2(const unsigned char *q, 
     out[1] = mc | ma;             // hi bit: C=2, A=3
     out[2] = ~(ma | mc | mg | mt);  // everything else is "N"
 }
+// 64 bases -> two triples with AVX-512BW byte compares straight into mask registers
+__attribute__((target("avx512f,avx512bw"))) inline void pack64_avx512(const unsigned char *q, uint32_t *out) {
+    const __m512i c = _mm512_and_si512(_mm512_loadu_si512((const void *) q), _mm512_set1_epi8((char) 0xDF));
+    const uint64_t ma = _mm512_cmpeq_epi8_mask(c, _mm512_set1_epi8('A')), mc = _mm512_cmpeq_epi8_mask(c, _mm512_set1_epi8('C'));
+    const uint64_t mg = _mm512_cmpeq_epi8_mask(c, _mm512_set1_epi8('G')), mt = _mm512_cmpeq_epi8_mask(c, _mm512_set1_epi8('T'));
+    const uint64_t lo = mg | ma, hi = mc | ma, nm = ~(ma | mc | mg | mt);
+    out[0] = (uint32_t) lo;
+    out[1] = (uint32_t) hi;
+    out[2] = (uint32_t) nm;
+    out[3] = (uint32_t) (lo >> 32);
+    out[4] = (uint32_t) (hi >> 32);
+    out[5] = (uint32_t) (nm >> 32);
+}
 #endif
 
 // one read -> triples; returns words written
@@ -596,7 +764,10 @@ inline uint64_t pack_one(const unsigned char *p, uint64_t len, uint32_t *out) {
     const uint64_t nw = (len + 31) / 32;
     uint64_t j = 0;
 #if defined(__x86_64__)
+    static const bool have_avx512 = __builtin_cpu_supports("avx512bw") && !getenv("TREW_NO_AVX512");
     static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx512)
+        for (; 32 * (j + 2) <= len; j += 2) pack64_avx512(p + 32 * j, out + 3 * j);
     if (have_avx2)
         for (; 32 * (j + 1) <= len; j++) pack32_avx2(p + 32 * j, out + 3 * j);
 #endif

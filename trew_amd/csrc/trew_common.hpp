@@ -40,11 +40,22 @@ struct DevBatch {
 
 // the worklist is a plain array of unit indices (reads / pairs) that survived the prefilter
 
+// words of DevTable::overflow (one 64-byte line of device counters, cleared by trew_hip_reset_tables)
+enum {
+    kDiagOverflow = 0,     // a row found the table AND the spill log full: counts were lost, collect fails
+    kDiagWorklistDrop = 1, // the prefilter had more survivors than the worklist holds (cannot happen: cap = batch capacity)
+    kDiagIntentDrop = 2,   // the pair driver logged more than 32 deferred emissions for one pair (cannot happen: <= 20)
+    kDiagInserted = 3,     // keys inserted into the narrow table (occupancy, trew_hip_table_pressure)
+    kDiagInsertedWide = 4, // keys inserted into the wide table
+    kDiagBadRow = 5,       // trew_hip_add_rows_device met a row with k / table out of range
+    kDiagWords = 16
+};
+
 struct DevTable {
     u64 *keys;    // 0 = empty
     u64 *counts;
     u32 log2_part_slots;  // slots per partition = 1 << log2_part_slots; 512 partitions
-    u32 *overflow;
+    u32 *overflow;        // kDiagWords counters, see above
     const struct DevWide *wide;  // device-resident descriptor of the wide-entry table (k > 32)
 };
 

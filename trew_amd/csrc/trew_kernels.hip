@@ -27,10 +27,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "trew_common.hpp"
 #include "trew_launch.hpp"
 #include "trew_synth.hpp"
+
+#ifndef TREW_FILTER_THREADS
+#define TREW_FILTER_THREADS 256
+#endif
 
 namespace trew {
 
@@ -462,16 +467,21 @@ __device__ __forceinline__ void filter_segment_uni(const u32 (&lo)[NW], const u3
     }
 }
 
-constexpr u32 kStage = 1024;  // unit indices a block stages in LDS before one global append
-constexpr u32 kDefer = 512;   // units set aside by the fast path (drained 256 at a time)
+// Block size of the prefilter.  Measured on MI355X (tools/filter_grid_ab.sh, profiles/r02/README.md): 64-thread blocks
+// (no block-level barrier at all) and 256-thread blocks run the same 0.70-0.72 ms on 10 M reads, and a variant with
+// wave-private staging lists was slower (95 VGPRs, 5 waves per SIMD) -- the kernel is bound by VALU issue, not by
+// its barriers.  Twice as many blocks as are resident is worth 5 % (the dispatcher back-fills the uneven tail).
+constexpr u32 kFilterThreads = TREW_FILTER_THREADS;
+constexpr u32 kStage = kFilterThreads == 256 ? 1024 : 192;  // unit indices a block stages in LDS before one global append
+constexpr u32 kDefer = 2 * kFilterThreads;                   // units set aside by the fast path (drained one block-full at a time)
 
 // Persistent blocks, grid-stride over the reads.  Survivors are staged in LDS and appended to
 // the worklist with ONE global atomic per flush: a per-wave atomic on the single worklist
 // counter caps at ~88 appends/us on MI355X (MI355X_MICROARCH.md "dequeue"), which was as long
 // as the whole k loop.
 template <int NW>
-__global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u32 *wl, u32 *wl_count, u32 wl_cap,
-                                                     u64 *dbg_masks, int dbg_slots, int max_seg) {
+__global__ __launch_bounds__(kFilterThreads) void filter_kernel(DevParams P, DevBatch B, u32 *wl, u32 *wl_count, u32 wl_cap,
+                                                                u64 *dbg_masks, int dbg_slots, int max_seg, u32 *diag) {
     __shared__ u32 stage[kStage];
     __shared__ u32 stage_n, flush_base;
     if (threadIdx.x == 0) stage_n = 0;
@@ -482,8 +492,12 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
             if (threadIdx.x == 0) flush_base = atomicAdd(wl_count, n);
             __syncthreads();
             const u32 fb = flush_base;
-            for (u32 i = threadIdx.x; i < n; i += blockDim.x)
-                if (fb + i < wl_cap) wl[fb + i] = stage[i];
+            for (u32 i = threadIdx.x; i < n; i += blockDim.x) {
+                if (fb + i < wl_cap)
+                    wl[fb + i] = stage[i];
+                else
+                    atomicAdd(&diag[kDiagWorklistDrop], 1u);  // surfaced by trew_hip_collect: never silent
+            }
             __syncthreads();
             if (threadIdx.x == 0) stage_n = 0;
         }
@@ -498,10 +512,10 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
             u32 sb = 0;
             if ((int) lane == leader) sb = atomicAdd(&stage_n, (u32) __popcll(bal));
             sb = __shfl(sb, leader);
-            if (flag) stage[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = unit;  // < kStage: flushed below when > kStage-256
+            if (flag) stage[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = unit;  // < kStage: flushed below when > kStage - block size
         }
         __syncthreads();
-        if (stage_n > kStage - 256u) flush();
+        if (stage_n > kStage - kFilterThreads) flush();
     };
     const int nslots = mode_slots(P.mode);
     const int gmax_run = (P.flags & TREW_FLAG_DEBUG_NO_KLOOP) ? P.min_mer - 1 : P.max_mer;
@@ -556,9 +570,9 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
     };
 
     // One loop for both kinds of batch, so that the (large) general path is instantiated once:
-    // every round the block takes 256 fresh units; the fast path judges the N-free ones on the spot
+    // every round the block takes one fresh unit per thread; the fast path judges the N-free ones on the spot
     // and sets the others aside, a batch without uniform geometry sets all of them aside; whenever
-    // 256 units are waiting (or the input is exhausted) the general path drains them.
+    // a block-full of units is waiting (or the input is exhausted) the general path drains them.
     __shared__ u32 defer[kDefer];
     __shared__ u32 defer_n;
     __shared__ int2 thr_tab[kMaxSlots][65];  // [k-1]; one entry of padding for the read-ahead
@@ -640,14 +654,14 @@ __global__ __launch_bounds__(256) void filter_kernel(DevParams P, DevBatch B, u3
                     u32 sb = 0;
                     if ((int) lane == leader) sb = atomicAdd(&defer_n, (u32) __popcll(bal));
                     sb = __shfl(sb, leader);
-                    if (dfr) defer[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = (u32) unit;  // < kDefer: drained below at 256
+                    if (dfr) defer[sb + (u32) __popcll(bal & ((1ull << lane) - 1ull))] = (u32) unit;  // < kDefer: drained below at one block-full
                 }
             }
             append(active && !dfr && any != 0, (u32) unit);  // syncs the block
         }
         const u32 dn = defer_n;  // block-uniform: every add happened before the last barrier
-        if (dn >= 256u || (!more && dn > 0u)) {
-            const u32 take = dn < 256u ? dn : 256u;
+        if (dn >= kFilterThreads || (!more && dn > 0u)) {
+            const u32 take = dn < kFilterThreads ? dn : kFilterThreads;
             const u32 at = dn - take;
             const bool active2 = threadIdx.x < take;
             const u32 unit2 = active2 ? defer[at + threadIdx.x] : 0u;
@@ -689,7 +703,7 @@ __attribute__((noinline)) __device__ void table_spill(DevTable T, int table, int
         r.count = cnt;
         W.spill_rows[at] = r;
     } else {
-        atomicExch(T.overflow, 1u);
+        atomicExch(&T.overflow[kDiagOverflow], 1u);
     }
 }
 
@@ -706,10 +720,12 @@ __attribute__((noinline)) __device__ void table_add(DevTable T, int table, int k
         if (cur == 0) {
             u64 expected = 0;
             if (__hip_atomic_compare_exchange_strong(&T.keys[idx], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
                 cur = key;
-            else
+                atomicAdd(&T.overflow[kDiagInserted], 1u);  // occupancy, read by trew_hip_table_pressure (new keys are rare)
+            } else {
                 cur = expected;
+            }
         }
         if (cur == key) {
             __hip_atomic_fetch_add(&T.counts[idx], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -740,6 +756,7 @@ __attribute__((noinline)) __device__ void table_add_wide(DevTable T0, int table,
         if (t == 0) {
             const u64 prev = atomicCAS((unsigned long long *) &T.wtag[idx], 0ull, base);
             if (prev == 0) {
+                atomicAdd(&T0.overflow[kDiagInsertedWide], 1u);
                 atomicExch((unsigned long long *) &T.wlo[idx], lo);
                 atomicExch((unsigned long long *) &T.whi[idx], hi);
                 __threadfence();
@@ -1378,17 +1395,24 @@ __device__ __forceinline__ void cached_add(ExactSmem sm, DevTable T, int table, 
     const u32 slot = (u32) (hash64(gkey ^ ((u64) part << 40)) >> 20) & (kCacheSlots - 1u);
     u64 *ckey = sm_ckey(sm);
     u32 *cpart = sm_cpart(sm), *ccnt = sm_ccnt(sm);
-    u64 ek = ckey[slot];
+    // Claim and publish in two separated phases.  A lane that wins the CAS stores the partition bits of its key;
+    // a lane of the same wave that lost the CAS to an equal gkey then reads them.  The cache is wave-private (one
+    // wave per workgroup) and LDS operations of a wave execute in program order, so the only hazard is the
+    // compiler moving the load above the store: the workgroup-scope fence + wave barrier between the phases
+    // forbid that, and both accesses are atomic, so there is no data race in the formal sense either.
+    u64 ek = __hip_atomic_load(&ckey[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bool won = false;
     if (ek == 0) {
         const u64 prev = atomicCAS((unsigned long long *) &ckey[slot], 0ull, gkey);
-        if (prev == 0) {
-            cpart[slot] = part;  // LDS operations of one wave execute in order: visible to the read below
-            ek = gkey;
-        } else {
-            ek = prev;
-        }
+        won = prev == 0;
+        ek = won ? gkey : prev;
     }
-    if (ek == gkey && cpart[slot] == part)
+    if (won) __hip_atomic_store(&cpart[slot], part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const u32 spart = __hip_atomic_load(&cpart[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ek == gkey && spart == part)
         atomicAdd(&ccnt[slot], cnt);
     else
         table_add(T, table, k, word, (u64) cnt);
@@ -1431,16 +1455,35 @@ __attribute__((noinline)) __device__ void emit_k(ExactSmem sm, DevTable T, u32 n
     strand_canon = rfl((u32) strand_canon) != 0;
     const u32 lane = lane_id();
     PH_T0(t_ph);
-    for (u32 i = lane; i < n_items; i += 64) {
-        const u32 c = sm_cnt(sm)[i];
+    for (u32 base = 0; base < n_items; base += 64) {  // wave-uniform trip count: the de-duplication below is a wave operation
+        const u32 i = base + lane;
+        u32 c = i < n_items ? sm_cnt(sm)[i] : 0u;
+        WT w = 0;
         if (c) {
-            WT w = sm_canon<WT>(sm)[i];
+            w = sm_canon<WT>(sm)[i];
             if (strand_canon) {
                 const WT rc = min_rotation<WT>(revcomp(w, k), k);
                 w = rc < w ? rc : w;
             }
-            for (u32 tm = table_mask; tm; tm &= tm - 1) cached_add(sm, T, __ffs((int) tm) - 1, k, w, c);
         }
+        if (sizeof(WT) > 8 && k > 32 && strand_canon) {
+            // A class and its reverse-complement class reach this point with the SAME strand-canonical key, in
+            // two lanes of one wave.  In the wide table the lane that loses the slot claim waits for the winner's
+            // ready bit (table_add_wide) -- a sibling lane of a lock-step wave must never be that winner, so equal
+            // keys are merged here first (classes are distinct before canonicalisation: at most two lanes per key).
+            u64 rem = __ballot(c != 0);
+            while (rem) {
+                const int src = __ffsll((long long) rem) - 1;
+                const WT o = readlane_word(w, src);
+                const u64 eqm = __ballot(c != 0 && w == o);
+                const bool eq = (eqm >> lane) & 1ull;
+                const u32 tot = wave_sum_u32(eq ? c : 0u);
+                if (eq) c = (int) lane == src ? tot : 0u;
+                rem &= ~eqm;
+            }
+        }
+        if (c)
+            for (u32 tm = table_mask; tm; tm &= tm - 1) cached_add(sm, T, __ffs((int) tm) - 1, k, w, c);
     }
     PH_ADD(PH_EMIT, t_ph);
 }
@@ -2188,9 +2231,13 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
         return d;
     };
     auto add_intent = [&](int slot, int k, int b, int temp) {
-        if (k > 0 && n_int < 32) {
-            if (lane == n_int) my_intent = pack_intent(slot, k, b, temp);
-            n_int++;
+        if (k > 0) {
+            if (n_int < 32) {
+                if (lane == n_int) my_intent = pack_intent(slot, k, b, temp);
+                n_int++;
+            } else if (lane == 0) {
+                atomicAdd(&T.overflow[kDiagIntentDrop], 1u);  // at most 20 per pair today; a change that breaks this fails loudly in collect
+            }
         }
     };
     // resolve the intent list: destination tables per (temp, baseline); plain[] rotation-canonical
@@ -2337,7 +2384,13 @@ __device__ void run_pair(ExactSmem sm, const DevParams &P, const DevBatch &B, co
 // NW == 0: long segments, pruning happens inside eval_k instead.
 template <int NW, int MODE, typename WT>
 __global__ __launch_bounds__(64, (NW >= 10 ? 4 : 6)) void exact_kernel(DevParams P, DevBatch B, DevTable T, const u32 *wl,
-                                                   u32 *wl_count, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
+                                                   u32 *wl_count, u32 *wl_count_next, u32 wl_cap, SegResults R, u32 cap, u32 rawwords) {
+    // A slot owns two counter blocks and alternates between them: while this launch consumes one, its first wave
+    // clears the other for the slot's next submit (stream order puts that submit's prefilter after this kernel), so
+    // a submit needs no memset call.
+    if (blockIdx.x == 0 && wl_count_next) {
+        for (u32 i = lane_id(); i < (1u + 8u) * 32u; i += 64u) wl_count_next[i] = 0u;
+    }
     ExactSmem sm;
     sm.cap = cap;
     sm.rawwords = rawwords;
@@ -2472,7 +2525,13 @@ extern "C" int trew_debug_phases(unsigned long long *out, int reset) {
 // ------------------------------------------------------------------ table maintenance
 __global__ void table_add_rows_kernel(DevTable T, const trew_hip_row *rows, u64 n) {
     const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) table_add(T, rows[i].table, rows[i].k, ((u128) rows[i].word_hi << 64) | rows[i].word_lo, rows[i].count);
+    if (i >= n) return;
+    const trew_hip_row r = rows[i];
+    if (r.k < 1 || r.k > 64 || r.table < 0 || r.table >= TREW_NUM_TABLES || (r.k <= 32 && r.word_hi)) {
+        atomicAdd(&T.overflow[kDiagBadRow], 1u);
+        return;
+    }
+    if (r.count) table_add(T, r.table, r.k, ((u128) r.word_hi << 64) | r.word_lo, r.count);
 }
 
 // compaction of the sparse table into rows (collect): one atomic per occupied slot
@@ -2598,28 +2657,36 @@ int pick_nw(u32 max_seg_len) {
 }
 
 hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevParams &P, const DevBatch &B, u32 *wl, u32 *wl_count,
-                         u32 wl_cap, u64 *dbg_masks, int dbg_slots) {
+                         u32 wl_cap, u64 *dbg_masks, int dbg_slots, u32 *diag) {
     const int nw = pick_nw(max_seg_len);
     const int max_seg = (int) std::min<u32>(max_seg_len, (u32) (32 * nw - 1));
     if (B.n_units == 0) return hipSuccess;
-    const u32 threads = 256;
-    u64 blocks = (B.n_units + threads - 1) / threads;
-    const u64 persistent = (u64) n_cu * 8ull;  // grid-stride blocks, a few per CU
-    if (blocks > persistent) blocks = persistent;
-    dim3 g((u32) blocks), b(threads);
-    switch (nw) {
-    case 3: hipLaunchKernelGGL(filter_kernel<3>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
-    case 5: hipLaunchKernelGGL(filter_kernel<5>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
-    case 10: hipLaunchKernelGGL(filter_kernel<10>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
-    default: hipLaunchKernelGGL(filter_kernel<32>, g, b, 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg); break;
+    typedef void (*kern_t)(DevParams, DevBatch, u32 *, u32 *, u32, u64 *, int, int, u32 *);
+    const kern_t fn = nw == 3 ? filter_kernel<3> : nw == 5 ? filter_kernel<5> : nw == 10 ? filter_kernel<10> : filter_kernel<32>;
+    const u32 threads = kFilterThreads;
+    // Persistent blocks with a static, grid-strided share of the reads each; twice the resident number of blocks
+    // (78 VGPRs -> 6 waves per SIMD for 150-bp reads), so that CUs whose blocks finish early pick up another one.
+    static thread_local kern_t cached_fn = nullptr;
+    static thread_local int cached_per_cu = 0;
+    int per_cu = cached_per_cu;
+    if (cached_fn != fn) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fn, (int) threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        per_cu *= 2;
+        if (const char *e = getenv("TREW_FILTER_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments only
+        cached_fn = fn;
+        cached_per_cu = per_cu;
     }
+    u64 blocks = (B.n_units + threads - 1) / threads;
+    const u64 persistent = (u64) n_cu * (u64) per_cu;
+    if (blocks > persistent) blocks = persistent;
+    hipLaunchKernelGGL(fn, dim3((u32) blocks), dim3(threads), 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg, diag);
     return hipGetLastError();
 }
 
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_lds_bytes(cap, rawwords, wordbytes); }
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
-                        const u32 *wl, u32 *wl_count, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
+                        const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
     const bool wide = P.max_mer > 32;  // 128-bit words, k_mer_check_128 (kmer.cpp:100, 180)
@@ -2627,7 +2694,7 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
     const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
-    typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32, SegResults, u32, u32);
+    typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
 #define TREW_PICK_MODE(NWV, WTV)                                                      \
     switch (P.mode) {                                                                 \
@@ -2667,8 +2734,12 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
         cached_per_cu = per_cu;
     }
     per_cu = per_cu > 32 ? 32 : per_cu;
-    const u32 grid = (u32) std::min<u64>((u64) n_cu * (u64) per_cu, std::max<u64>(n_units, 1));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_cap, R, cap, rawwords);
+    // Self-scheduling waves: any grid size is correct, it only has to be large enough to keep the chip busy.  A big
+    // batch gets every resident wave slot; a small one (the CLI's ~10^5-read batches, of which 1-2 % survive the
+    // prefilter) one wave per 16 units, so that a launch does not start thousands of waves that find the queue empty.
+    const u64 full = (u64) n_cu * (u64) per_cu;
+    const u32 grid = (u32) std::min<u64>(full, std::max<u64>(n_units / 16, 64));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64), lds, st, P, B, T, wl, wl_count, wl_count_next, wl_cap, R, cap, rawwords);
     return hipGetLastError();
 }
 

@@ -10,9 +10,12 @@ hash tables whose slot layout differs per GPU, so they are made reducible first:
   4. ONE all_reduce(sum) of that vector (RCCL over xGMI with backend "nccl";
      gloo in the CPU tests).
 
-allreduce_rows_into_table() is the variant bench.py uses: the rows are all_gathered and merged by
-the device count table itself (the table IS a sum-merge structure), which costs a few ms instead
-of building a dictionary of ~10^5 keys on the host.
+allreduce_table_device() is what bench.py calls for N > 1: the rows are compacted on the device,
+all_gathered as device tensors (RCCL) and merged by the device count table itself (the table IS a
+sum-merge structure) -- no host round trip, no dictionary.  allreduce_rows_into_table() is the same
+exchange with host-side row arrays (gloo rehearsals and the CPU tests); allreduce_tables() /
+allreduce_rows() are the dictionary + ONE all_reduce formulation of SURVEY 8(e), kept as the
+reference the other two are tested against.
 
 The payload is KB..MB, i.e. latency-bound; the per-link xGMI bandwidth does not bind.
 """
@@ -166,6 +169,49 @@ def allreduce_rows_into_table(ctx, rows, device="cpu", group=None):
     others = [gathered[r][: sizes[r]].cpu().numpy().reshape(-1).view(ROW_DTYPE) for r in range(world) if r != rank and sizes[r]]
     if others:
         ctx.add_rows(np.concatenate(others))
+    return ctx.collect_rows()
+
+
+def allreduce_table_device(ctx, device, group=None, force_collectives=False):
+    """The reduction bench.py uses for N > 1 with backend "nccl" (= RCCL): nothing leaves HBM until the final rows.
+
+      1. trew_hip_collect_device compacts this rank's table into a device tensor (32 B per row: table, k, word, count);
+      2. all_gather of the row counts, all_gather of the (padded) row tensors -- RCCL over xGMI, KB..MB, latency-bound;
+      3. every OTHER rank's rows are added into this rank's device table (trew_hip_add_rows_device: one kernel of
+         atomic adds per peer) -- the table is the sum-merge structure, no dictionary is built anywhere;
+      4. trew_hip_collect returns the merged rows; every rank's table now holds the global sums.
+
+    ctx: trew_amd.capi.TrewHip.  device: the torch device of ctx's GPU.  force_collectives issues the two
+    all_gathers even at world size 1 (the one-GPU test of the RCCL path)."""
+    from .capi import ROW_DTYPE
+
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    if not on or (world == 1 and not force_collectives):
+        return ctx.collect_rows()
+    rank = dist.get_rank(group)
+    words = ROW_DTYPE.itemsize // 8
+    cap = getattr(ctx, "_dev_rows_cap", 1 << 16)
+    while True:
+        buf = torch.empty((cap, words), dtype=torch.int64, device=device)
+        n = ctx.collect_device(buf.data_ptr(), cap)
+        if n <= cap:
+            break
+        cap = ctx._dev_rows_cap = n + 4096
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=device), group=group)
+    sizes = [int(x) for x in sizes.cpu().tolist()]
+    n_max = max(max(sizes), 1)
+    local = torch.zeros((n_max, words), dtype=torch.int64, device=device)
+    local[:n] = buf[:n]
+    gathered = torch.empty((world * n_max, words), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    torch.cuda.synchronize(device)
+    if not torch.equal(gathered[rank * n_max: rank * n_max + n], buf[:n]):
+        raise RuntimeError("all_gather returned this rank's own rows altered")
+    for r in range(world):
+        if r != rank and sizes[r]:
+            ctx.add_rows_device(gathered[r * n_max:].data_ptr(), sizes[r])
     return ctx.collect_rows()
 
 
