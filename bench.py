@@ -82,7 +82,12 @@ def committed_profile(n, L):
             for kern in ("filter_kernel", "exact_kernel"):
                 if kern in r["kernel"]:
                     cnt.setdefault(kern, {})[r["counter"]] = float(r["avg_per_dispatch"])
-        for r in csv.DictReader(open(os.path.join(prof, "kernel_stats_final.csv"))):
+        # durations of the kernels ALONE on the device (the PMC passes serialise dispatches): the one-stream trace when
+        # the round has one, else the round's only trace
+        stats = os.path.join(prof, "kernel_stats_serial.csv")
+        if not os.path.exists(stats):
+            stats = os.path.join(prof, "kernel_stats_final.csv")
+        for r in csv.DictReader(open(stats)):
             for kern in ("filter_kernel", "exact_kernel"):
                 if kern in r["Name"]:
                     dur[kern] = float(r["AverageNs"])
@@ -101,7 +106,8 @@ def committed_profile(n, L):
                 "cycles_per_valu_inst": round(active / c["SQ_INSTS_VALU"], 2) if c.get("SQ_INSTS_VALU") else None,
             }
         valu["cycles_per_inst_by_class"] = rates["cycles_per_wave_inst"]
-        valu["source"] = "profiles/%s/pmc_summary_final.csv, kernel_stats_final.csv; profiles/valu_rate.json (tools/valu_rate.hip on the box)" % rnd
+        valu["source"] = "profiles/%s/pmc_summary_final.csv (counters), %s (durations alone on the device); profiles/valu_rate.json (tools/valu_rate.hip on the box)" % (
+            rnd, os.path.basename(stats))
     except (OSError, KeyError, ValueError):
         valu = {}
     return traffic, (valu or None), rnd

@@ -87,3 +87,23 @@ def test_counts_wrap_like_the_reference_uint32_maps(harness):
     rnd = random.Random(99)
     files = [("/big%d" % i, _random_tables(rnd, 32, big=True)) for i in range(3)]
     assert _run(harness, files, 5) == _expected(files, 5)
+
+
+@pytest.mark.parametrize("low_fb,high_fb", [((100, 60), (10, 50)), ((100, 60), (50, 10)), ((40, 20), (10, 20)), ((30, 30), (5, 50)),
+                                             ((0, 0), (12, 40)), ((20, 10), (0, 0)), ((60, 20), (20, 60)), ((20, 60), (90, 30))])
+def test_putative_trm_strand_decision(harness, low_fb, high_fb):
+    """final_process_output's strand ladder (kmer.cpp:2603-2650): agreement, one-sided verdicts, opposite verdicts
+    (ratio by cross multiplication, ties by total), no verdict."""
+    w = O.rot_seq(O.four_to_int("TTAGGG"), 6)
+    rc = O.rot_seq(O.revcomp(w, 6), 6)
+    fwd_key, bwd_key = (w, rc) if w < rc else (rc, w)
+    t = {name: {} for name in capi.TABLE_NAMES}
+    for name, (f, b) in (("low", low_fb), ("high", high_fb)):
+        if f:
+            t["forward_" + name][(6, fwd_key)] = f
+        if b:
+            t["forward_" + name][(6, bwd_key)] = b
+    other = O.rot_seq(O.four_to_int("TTTAGGG"), 7)
+    t["both_high"][(7, min(other, O.rot_seq(O.revcomp(other, 7), 7)))] = 25  # keeps the section non-trivial
+    files = [("/s.fastq", t)]
+    assert _run(harness, files, 5) == _expected(files, 5)

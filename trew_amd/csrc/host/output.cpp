@@ -205,6 +205,26 @@ std::map<KmerSeq, uint32_t> get_score_map(const FinalFastqData &total_result) {
     return score;
 }
 
+static inline int sign_of(int64_t v) { return v > 0 ? 1 : (v < 0 ? -1 : 0); }
+
+enum class StrandRule { none, low, high, agree, conflict };
+// [sign in the low table + 1][sign in the high table + 1]
+static const StrandRule kStrandRule[3][3] = {
+    /* low says -  */ {StrandRule::agree, StrandRule::low, StrandRule::conflict},
+    /* low says ?  */ {StrandRule::high, StrandRule::none, StrandRule::high},
+    /* low says +  */ {StrandRule::conflict, StrandRule::low, StrandRule::agree},
+};
+
+// Two tables disagree about the strand: trust the one whose minority/majority ratio is smaller (compared by cross
+// multiplication, as the reference does); equal ratios go to the table with more reads, then to the high table.
+static bool purer_table_is_low(const FinalData &low, const FinalData &high) {
+    const int64_t l_major = std::max(low.forward, low.backward), l_minor = std::min(low.forward, low.backward);
+    const int64_t h_major = std::max(high.forward, high.backward), h_minor = std::min(high.forward, high.backward);
+    const int64_t lhs = l_minor * h_major, rhs = h_minor * l_major;
+    if (lhs != rhs) return lhs < rhs;
+    return l_major + l_minor > h_major + h_minor;
+}
+
 void final_process_output(FinalFastqData &total_high, FinalFastqData &total_low, FILE *out) {
     bool max_cnt_check = false;
     for (const auto &kv : total_high)
@@ -231,29 +251,20 @@ void final_process_output(FinalFastqData &total_high, FinalFastqData &total_low,
         if (il != total_low.end()) low_result = il->second;
         auto ih = total_high.find(kv.first);
         if (ih != total_high.end()) high_result = ih->second;
-        int bonus = 0;
-        const int high_dir = high_result.forward > high_result.backward ? 1 : (high_result.forward < high_result.backward ? -1 : 0);
-        const int low_dir = low_result.forward > low_result.backward ? 1 : (low_result.forward < low_result.backward ? -1 : 0);
-        int final_dir;
-        if (low_dir != 0 && low_dir == high_dir) {
+        // Strand of the motif from the two baselines' tables (kmer.cpp:2603-2650), as a decision table over the
+        // sign of forward - backward in each: agreement earns a bonus point, a one-sided verdict is taken as it
+        // is, and two opposite verdicts go to the table whose minority strand is relatively smaller.
+        const int low_dir = sign_of(low_result.forward - low_result.backward), high_dir = sign_of(high_result.forward - high_result.backward);
+        int bonus = 0, final_dir = 0;
+        switch (kStrandRule[low_dir + 1][high_dir + 1]) {
+        case StrandRule::none: break;
+        case StrandRule::low: final_dir = low_dir; break;
+        case StrandRule::high: final_dir = high_dir; break;
+        case StrandRule::agree:
+            final_dir = low_dir;
             bonus += 1;
-            final_dir = low_dir;
-        } else if (low_dir == 0 && high_dir != 0) {
-            final_dir = high_dir;
-        } else if (low_dir != 0 && high_dir == 0) {
-            final_dir = low_dir;
-        } else if (low_dir != high_dir && (low_result.forward > 0 || low_result.backward > 0 || high_result.forward > 0 || high_result.backward > 0)) {
-            if (low_result.forward < low_result.backward) std::swap(low_result.forward, low_result.backward);
-            if (high_result.forward < high_result.backward) std::swap(high_result.forward, high_result.backward);
-            if (low_result.backward * high_result.forward == high_result.backward * low_result.forward) {
-                final_dir = (low_result.forward + low_result.backward > high_result.forward + high_result.backward) ? low_dir : high_dir;
-            } else if (low_result.backward * high_result.forward < high_result.backward * low_result.forward) {
-                final_dir = low_dir;
-            } else {
-                final_dir = high_dir;
-            }
-        } else {
-            final_dir = 0;
+            break;
+        case StrandRule::conflict: final_dir = purer_table_is_low(low_result, high_result) ? low_dir : high_dir; break;
         }
         const int dna_cnt = get_dna_count(kv.first.seq, kv.first.k);
         if (dna_cnt > 2) bonus += 1;

@@ -99,12 +99,14 @@ struct FileReader {
     _exit(EXIT_FAILURE);
 }
 
-static FileReader open_reader(const char *file_name, bool is_gz) {
+static FileReader open_reader(const char *file_name, bool is_gz, int n_threads) {
     FileReader r;
     r.is_gz = is_gz;
     if (is_gz && BgzfReader::sniff(file_name)) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        r.bgzf = new BgzfReader(file_name, (int) std::min(8u, std::max(2u, hw / 2)));
+        // inflate is the bottleneck of compressed input and the packers are nearly idle beside it: as many inflate
+        // threads as the user gave the run (-t), within what the machine has
+        const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+        r.bgzf = new BgzfReader(file_name, (int) std::min<unsigned>(hw, (unsigned) std::max(2, std::min(n_threads, 32))));
         if (!r.bgzf->ok()) open_failed(file_name);
         return r;
     }
@@ -639,9 +641,10 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
         ChunkQueue q(qcap);
         std::vector<std::thread> th;
         for (auto &w : s->workers) th.emplace_back(worker_loop, s, &w, &q);
-        FileReader f1 = open_reader(name1, gz1);
+        const int inflaters = s->mode == TREW_MODE_PAIR ? std::max(2, cfg.NUM_THREAD / 2) : cfg.NUM_THREAD;
+        FileReader f1 = open_reader(name1, gz1, inflaters);
         if (s->mode == TREW_MODE_PAIR) {
-            FileReader f2 = open_reader(name2, gz2);
+            FileReader f2 = open_reader(name2, gz2, inflaters);
             read_pair_fastq_thread(f1, f2, &q);
             f2.close();
         } else {
