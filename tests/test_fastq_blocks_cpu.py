@@ -66,3 +66,28 @@ def test_blocks_find_the_reference_lines(harness, tmp_path, name):
         if block < 7 and len(data) > 20000:
             continue  # a block per byte is pointless on the big cases
         assert run(harness, path, block, threads) == want, (name, block, threads)
+
+
+def test_paired_reader_helpers(harness, tmp_path):
+    """LineIndex + LineCursor (the paired block reader): mates are located by read index -- lines 4r .. 4r+3 of each
+    file -- from per-block newline counts, for any block size and any split of the read range into items; the two
+    files have different line lengths, so their blocks do not line up."""
+    rnd = random.Random(11)
+    recs1, recs2 = [], []
+    for i in range(700):
+        n1, n2 = rnd.choice([0, 36, 150, 151]), rnd.choice([1, 75, 150, 250])
+        recs1.append("@r%d/1\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGTN") for _ in range(n1)), "I" * n1))
+        recs2.append("@read_number_%d/2 extra\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGT") for _ in range(n2)), "#" * n2))
+    d1, d2 = "".join(recs1).encode(), "".join(recs2).encode()
+    for tag, (a, b) in {"full": (d1, d2), "no_final_newline": (d1[:-1], d2)}.items():
+        p1, p2 = str(tmp_path / (tag + "_1.fastq")), str(tmp_path / (tag + "_2.fastq"))
+        open(p1, "wb").write(a)
+        open(p2, "wb").write(b)
+        w1, w2 = reference_rule(a), reference_rule(b)
+        for block, per_item in [(64, 1), (333, 7), (4096, 100), (1 << 22, 65536)]:
+            r = subprocess.run([harness, "pair", p1, p2, str(block), str(per_item)], capture_output=True, text=True, check=True)
+            lines = r.stdout.splitlines()
+            assert lines[0] == "%d %d" % (a.count(b"\n"), b.count(b"\n"))
+            got = [tuple(int(x) for x in line.split()) for line in lines[1:]]
+            n = min(len(w1), len(w2))
+            assert got == [w1[i] + w2[i] for i in range(n)], (tag, block, per_item)

@@ -113,6 +113,34 @@ def test_cli_pair(tmp_path):
     assert run("short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2, "-t", "4") == want
 
 
+def test_cli_pair_block_parallel(tmp_path):
+    """Two plain files: the paired block reader (mates located by read index from per-block newline counts, read ranges
+    claimed by the workers) against the oracle and against the reference-shaped serial reader; mates of different lengths,
+    more pairs than one work item (65 536), a missing final newline in one file still pairs (the counts differ by one
+    newline... which the reference reports as a mismatch: so does this reader)."""
+    import random
+
+    rnd = random.Random(5)
+    b1, b2, st, nd = capi.synth_pair_ascii(20250218, 500, 150000, 150)
+    r1 = [b1[s:e + 1][: rnd.choice([150, 150, 140, 101])] for s, e in zip(st, nd)]
+    r2 = [b2[s:e + 1][: rnd.choice([150, 150, 150, 128])] for s, e in zip(st, nd)]
+    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    write_fastq(f1, r1)
+    write_fastq(f2, r2)
+    want = expected([(f1, O.run_pair(O.OracleParams(), r1, r2))], 5)
+    for extra in (["-t", "4"], ["-t", "9"], ["-t", "3", "--serial_reader"]):
+        assert run("short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2, *extra) == want
+    r = subprocess.run([TREW, "short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2, "-t", "4", "--stats"], capture_output=True, text=True, timeout=300)
+    assert "block-parallel paired reader" in r.stderr and "%d reads" % (2 * len(r1)) in r.stderr
+    # record counts that differ: the reference's message and exit status (kmer.cpp:1112-1114), from both readers
+    f3 = str(tmp_path / "r2_short.fastq")
+    write_fastq(f3, r2[:-3])
+    for extra in ([], ["--serial_reader"]):
+        r = subprocess.run([TREW, "short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f3, *extra], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and r.stdout == ""
+        assert "Mismatched record counts between files" in r.stderr or (extra and "Paired-end error" in r.stderr)
+
+
 def test_cli_long(tmp_path):
     from test_gpu_parity import _long_reads
 

@@ -19,6 +19,26 @@ for t in (2, 4, 8, 16):
     r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", path, "-t", str(t), "--stats"], capture_output=True, text=True)
     print("threads", t, " | ".join(x for x in r.stderr.strip().splitlines() if x.startswith("[trew]")) if r.stderr else r.returncode)
 
+# paired files (config 3's shape): two plain FASTQ files, mates matched by read index
+npair = 16_000_000
+b1, b2, _, _ = capi.synth_pair_ascii(20250218, 0, npair, 150)
+for name, bb in (("/tmp/e2e_r1.fastq", b1), ("/tmp/e2e_r2.fastq", b2)):
+    bm = np.frombuffer(bb, dtype=np.uint8).reshape(npair, 151)
+    rp = np.zeros((npair, 3 + 151 + 2 + 151), dtype=np.uint8)
+    rp[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+    rp[:, 3:154] = bm
+    rp[:, 154:156] = np.frombuffer(b"+\n", dtype=np.uint8)
+    rp[:, 156:306] = ord("I")
+    rp[:, 306] = ord("\n")
+    rp.tofile(name)
+    del rp, bm
+del b1, b2
+for t in (8, 16):
+    for extra in ([], ["--serial_reader"]):
+        r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", "--paired_end", "--fq1", "/tmp/e2e_r1.fastq", "--fq2", "/tmp/e2e_r2.fastq",
+                            "-t", str(t), "--stats", *extra], capture_output=True, text=True)
+        print("pairs threads", t, " ".join(extra), " | ".join(x for x in r.stderr.strip().splitlines() if x.startswith("[trew]")) if r.stderr else r.returncode)
+
 # the same file as plain gzip (one member: gzread on one thread, as the reference does) and as BGZF
 # (independent 64 KiB members: inflated on several threads by host/bgzf_reader.hpp)
 import gzip, zlib, struct
@@ -35,6 +55,6 @@ with open(bg, "wb") as f:
         f.write(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(body) + 8 - 1))
         f.write(body)
         f.write(struct.pack("<II", zlib.crc32(c) & 0xFFFFFFFF, len(c) & 0xFFFFFFFF))
-for name, p in (("plain gzip", gz), ("BGZF", bg)):
-    r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", p, "-t", "8", "--stats"], capture_output=True, text=True)
+for name, p, t in (("plain gzip", gz, 8), ("BGZF -t 8", bg, 8), ("BGZF -t 16", bg, 16)):
+    r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "short", "5", "32", p, "-t", str(t), "--stats"], capture_output=True, text=True)
     print(name, " | ".join(x for x in r.stderr.strip().splitlines() if x.startswith("[trew]")) if r.stderr else r.returncode)

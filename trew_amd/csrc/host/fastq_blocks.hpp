@@ -52,6 +52,93 @@ inline size_t scan_newlines(const char *p, size_t n, uint32_t *out) {
     return cnt;
 }
 
+// number of '\n' in p[0, n)
+#if defined(__x86_64__)
+__attribute__((target("avx2,popcnt"))) inline size_t count_newlines_avx2(const char *p, size_t n) {
+    size_t cnt = 0, i = 0;
+    const __m256i nl = _mm256_set1_epi8('\n');
+    for (; i + 32 <= n; i += 32) cnt += (size_t) __builtin_popcount((uint32_t) _mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *) (p + i)), nl)));
+    for (; i < n; i++) cnt += p[i] == '\n';
+    return cnt;
+}
+#endif
+inline size_t count_newlines(const char *p, size_t n) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+    if (have_avx2) return count_newlines_avx2(p, n);
+#endif
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; i++) cnt += p[i] == '\n';
+    return cnt;
+}
+
+// Walks the newlines of a mapped file from a byte position on, a window at a time (the paired reader: a worker
+// needs lines 4r .. 4r+3 of read r in BOTH files, and knows from the per-block newline counts where line 4r starts).
+struct LineCursor {
+    const char *base = nullptr;
+    size_t size = 0, win_lo = 0, win_hi = 0, idx = 0, cnt = 0;
+    std::vector<uint32_t> nl;
+    static constexpr size_t kWindow = (size_t) 1 << 18;
+    void init(const char *b, size_t n, size_t pos) {
+        base = b;
+        size = n;
+        win_lo = win_hi = pos;
+        idx = cnt = 0;
+        if (nl.size() < kWindow) nl.resize(kWindow);
+    }
+    // absolute offset of the next '\n' at or after the cursor, -1 at the end of the file
+    int64_t next() {
+        while (idx == cnt) {
+            if (win_hi >= size) return -1;
+            win_lo = win_hi;
+            win_hi = win_lo + kWindow < size ? win_lo + kWindow : size;
+            cnt = scan_newlines(base + win_lo, win_hi - win_lo, nl.data());
+            idx = 0;
+        }
+        return (int64_t) (win_lo + nl[idx++]);
+    }
+};
+
+// Per-block newline counts of one mapped file (the paired reader's first pass) and the lookup they allow.
+struct LineIndex {
+    const char *base = nullptr;
+    size_t size = 0, block = 0, n_blocks = 0;
+    std::vector<int64_t> before;  // before[b] = newlines in [0, start of block b); before[n_blocks] = total
+    void init(const char *b, size_t n, size_t blk) {
+        base = b;
+        size = n;
+        block = blk;
+        n_blocks = (n + blk - 1) / blk;
+        before.assign(n_blocks + 1, 0);
+    }
+    void count_block(size_t b) {  // any thread, any order; before[b + 1] holds the block's own count until finish()
+        const size_t lo = b * block, hi = lo + block < size ? lo + block : size;
+        before[b + 1] = (int64_t) count_newlines(base + lo, hi - lo);
+    }
+    void finish() {
+        for (size_t b = 0; b < n_blocks; b++) before[b + 1] += before[b];
+    }
+    int64_t total() const { return before[n_blocks]; }
+    // byte offset at which line number `line` (0-based) starts; the line must exist or be the one past the last newline
+    size_t line_start(int64_t line, std::vector<uint32_t> &scratch) const {
+        if (line <= 0) return 0;
+        const int64_t want = line - 1;  // the newline that closes the previous line
+        size_t lo = 0, hi = n_blocks;   // block with before[b] <= want < before[b + 1]
+        while (lo + 1 < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (before[mid] <= want)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const size_t blo = lo * block, bhi = blo + block < size ? blo + block : size;
+        if (scratch.size() < block) scratch.resize(block);
+        const size_t cnt = scan_newlines(base + blo, bhi - blo, scratch.data());
+        const size_t j = (size_t) (want - before[lo]);
+        return j < cnt ? blo + scratch[j] + 1 : size;
+    }
+};
+
 struct BlockScan {
     const char *base = nullptr;
     size_t size = 0, block = 0, n_blocks = 0;

@@ -3,14 +3,14 @@
 //
 // Two pipelines, same results:
 //
-//  * serial reader (gzip / BGZF input, paired files): the shape of the reference
+//  * serial reader (gzip / BGZF input): the shape of the reference
 //    (kmer.cpp:987-1476) -- one producer reading 4 MiB chunks (LENGTH, kmer.h:8), sequence lines found by
 //    counting newlines (num & 3 == 2), a sequence line split across two chunks carried over, pairs
 //    re-synchronised by read index; NUM_THREAD-1 consumers.  A consumer does not scan the reads itself: it
 //    packs the chunk into pinned memory and submits it to its own HIP stream (trew_hip_submit), so
 //    decode/pack of chunk i+1 overlaps the device scan of chunk i.
 //
-//  * block-parallel reader (plain FASTQ, single-end and long mode): the file is mapped and cut into 4 MiB
+//  * block-parallel reader (plain FASTQ; paired files have their own variant further down): the file is mapped and cut into 4 MiB
 //    blocks that the NUM_THREAD-1 workers claim in file order.  A worker records the newlines of its block,
 //    learns the line number its block starts at from its predecessor (a chain of additions, the only serial
 //    part), and then packs the sequence lines that END in its block -- a line that starts in an earlier
@@ -580,30 +580,150 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
     if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");
 }
 
+// ------------------------------------------------------------------ block-parallel reader, paired files
+// Mates are matched by read index (read r = lines 4r .. 4r+3 of each file, read_pair_fastq_thread, kmer.cpp:1040-1164).
+// Pass 1 counts the newlines of every 4 MiB block of both files (all workers, any order); with the prefix sums a worker
+// finds where any line starts.  Pass 2: workers claim ranges of read indices, walk the two files side by side from the
+// start of that range and pack the pairs.  No carry-over, no re-synchronisation: both fall out of the line numbers.
+struct PairJob {
+    LineIndex index[2];
+    std::atomic<size_t> next_block{0}, next_item{0};
+    size_t n_pairs = 0, pairs_per_item = 1 << 16;
+};
+
+static void pair_count_loop(PairJob *job) {
+    const size_t n0 = job->index[0].n_blocks, total = n0 + job->index[1].n_blocks;
+    for (;;) {
+        const size_t i = job->next_block.fetch_add(1);
+        if (i >= total) break;
+        if (i < n0)
+            job->index[0].count_block(i);
+        else
+            job->index[1].count_block(i - n0);
+    }
+}
+
+static void pair_worker_loop(Scanner *s, Worker *w, PairJob *job) {
+    trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    LineCursor cur[2];
+    std::vector<int64_t> st[2], nd[2];
+    for (;;) {
+        const size_t item = job->next_item.fetch_add(1);
+        const size_t r0 = item * job->pairs_per_item;
+        if (r0 >= job->n_pairs) break;
+        const size_t r1 = std::min(job->n_pairs, r0 + job->pairs_per_item);
+        const clk::time_point t0 = clk::now();
+        for (int m = 0; m < 2; m++) {
+            cur[m].init(job->index[m].base, job->index[m].size, job->index[m].line_start((int64_t) (4 * r0), w->nl));
+            st[m].clear();
+            nd[m].clear();
+            for (size_t r = r0; r < r1; r++) {
+                const int64_t a = cur[m].next(), b = cur[m].next(), x = cur[m].next(), y = cur[m].next();
+                if (a < 0 || b < 0) die("internal error: the paired reader ran past the end of a file");
+                (void) x;
+                (void) y;  // the last record may lack its final newline(s): the sequence line is complete
+                if (b - a - 1 > MAX_SEQ)  // the reference leaves pair mode unchecked
+                    die("This mode is designed for short-read sequencing. Please use 'trew long'.");
+                st[m].push_back(a + 1);
+                nd[m].push_back(b - 1);
+            }
+        }
+        const clk::time_point t1 = clk::now();
+        w->t_scan += secs(t0, t1);
+        // as many pairs per batch as the slot's buffers hold
+        for (size_t at = 0; at < st[0].size();) {
+            size_t n = 0;
+            uint64_t words = 0;
+            while (at + n < st[0].size() && 2 * (n + 1) <= w->reads_cap) {
+                const uint64_t need = 3ull * (((uint64_t) (nd[0][at + n] - st[0][at + n] + 1) + 31) / 32) + 3ull * (((uint64_t) (nd[1][at + n] - st[1][at + n] + 1) + 31) / 32);
+                if (words + need > w->words_cap) break;
+                words += need;
+                n++;
+            }
+            const clk::time_point tw = clk::now();
+            if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
+            const clk::time_point t2 = clk::now();
+            const uint64_t n_reads = 2 * n;
+            const uint64_t nw = trew_pack_pairs(job->index[0].base, st[0].data() + at, nd[0].data() + at, job->index[1].base, st[1].data() + at, nd[1].data() + at, n,
+                                                w->h_buf + 2 * n_reads, w->words_cap, w->h_buf, w->h_buf + n_reads);
+            const clk::time_point t3 = clk::now();
+            submit_packed(s, w, w->h_buf + 2 * n_reads, w->h_buf, w->h_buf + n_reads, n_reads, nw);
+            w->t_wait += secs(tw, t2);
+            w->t_pack += secs(t2, t3);
+            w->t_submit += secs(t3, clk::now());
+            at += n;
+        }
+    }
+    if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");
+}
+
+struct Mapping {
+    void *p = MAP_FAILED;
+    size_t size = 0;
+    bool map(const char *name) {
+        const int fd = open(name, O_RDONLY);
+        if (fd < 0) open_failed(name);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) {
+            close(fd);
+            return false;
+        }
+        size = (size_t) st.st_size;
+        p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) return false;
+        (void) madvise(p, size, MADV_SEQUENTIAL);
+        (void) madvise(p, size, MADV_WILLNEED);
+        return true;
+    }
+    ~Mapping() {
+        if (p != MAP_FAILED) munmap(p, size);
+    }
+};
+
+// false when a file cannot be mapped: the caller falls back to the serial reader
+static bool run_pair_blocks(Scanner *s, const char *name1, const char *name2) {
+    Mapping m1, m2;
+    if (!m1.map(name1) || !m2.map(name2)) return false;
+    PairJob job;
+    job.index[0].init((const char *) m1.p, m1.size, (size_t) LENGTH);
+    job.index[1].init((const char *) m2.p, m2.size, (size_t) LENGTH);
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < s->workers.size(); i++) th.emplace_back(pair_count_loop, &job);
+        for (auto &t : th) t.join();
+    }
+    job.index[0].finish();
+    job.index[1].finish();
+    const long long num1 = job.index[0].total(), num2 = job.index[1].total();
+    if (num1 != num2) {  // kmer.cpp:1112-1114
+        fprintf(stderr, "Error: Mismatched record counts between files (num1: %lld, num2: %lld).\n", num1, num2);
+        fflush(stdout);
+        fflush(stderr);
+        _exit(EXIT_FAILURE);
+    }
+    job.n_pairs = (size_t) ((num1 + 2) / 4);  // sequence lines closed by a newline: line numbers 1, 5, 9, ...
+    std::vector<std::thread> th;
+    for (auto &w : s->workers) th.emplace_back(pair_worker_loop, s, &w, &job);
+    for (auto &t : th) t.join();
+    return true;
+}
+
 // maps the file and runs the block workers; false when the file cannot be mapped (empty file, special file):
 // the caller falls back to the serial reader
 static bool run_blocks(Scanner *s, const char *name, bool long_mode, int slice_length) {
-    const int fd = open(name, O_RDONLY);
-    if (fd < 0) open_failed(name);
-    struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0) {
-        close(fd);
-        return false;
-    }
-    void *m = mmap(nullptr, (size_t) st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) return false;
-    (void) madvise(m, (size_t) st.st_size, MADV_SEQUENTIAL);
-    (void) madvise(m, (size_t) st.st_size, MADV_WILLNEED);
+    Mapping m;
+    if (!m.map(name)) return false;
     BlockJob job;
-    job.scan.init((const char *) m, (size_t) st.st_size, (size_t) LENGTH);
+    job.scan.init((const char *) m.p, m.size, (size_t) LENGTH);
     job.scan.populate = true;
     job.long_mode = long_mode;
     job.slice_length = slice_length;
     std::vector<std::thread> th;
     for (auto &w : s->workers) th.emplace_back(block_worker_loop, s, &w, &job);
     for (auto &t : th) t.join();
-    munmap(m, (size_t) st.st_size);
     return true;
 }
 
@@ -635,6 +755,9 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
     if (s->mode != TREW_MODE_PAIR && !gz1 && !cfg.serial_reader) {
         done = run_blocks(s, name1, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
         if (done) how = "block-parallel reader";
+    } else if (s->mode == TREW_MODE_PAIR && !gz1 && !gz2 && !cfg.serial_reader) {
+        done = run_pair_blocks(s, name1, name2);
+        if (done) how = "block-parallel paired reader";
     }
     if (!done) {
         size_t qcap = cfg.QUEUE_SIZE >= 4 ? (size_t) (cfg.QUEUE_SIZE / 4) : 256;  // kmer.cpp:1274-1276; "unlimited" is capped at 1 GiB

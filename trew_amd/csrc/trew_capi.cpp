@@ -853,17 +853,19 @@ extern "C" int trew_synth_short_ascii(uint64_t seed, uint64_t first_read, uint64
 }
 
 extern "C" int trew_synth_pair_ascii(uint64_t seed, uint64_t first_pair, uint64_t n_pairs, uint32_t read_len, char *out1, char *out2) {
-    for (uint64_t r = 0; r < n_pairs; r++) {
-        const trew_synth::ReadClass c = trew_synth::read_class(seed, first_pair + r);
-        char *o1 = out1 + r * (uint64_t) (read_len + 1);
-        char *o2 = out2 + r * (uint64_t) (read_len + 1);
-        for (uint32_t p = 0; p < read_len; p++) {
-            o1[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 0, p, read_len));
-            o2[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 1, p, read_len));
+    parallel_reads(n_pairs, [=](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            const trew_synth::ReadClass c = trew_synth::read_class(seed, first_pair + r);
+            char *o1 = out1 + r * (uint64_t) (read_len + 1);
+            char *o2 = out2 + r * (uint64_t) (read_len + 1);
+            for (uint32_t p = 0; p < read_len; p++) {
+                o1[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 0, p, read_len));
+                o2[p] = trew_synth::base_char(trew_synth::pair_base(seed, first_pair + r, c, 1, p, read_len));
+            }
+            o1[read_len] = '\n';
+            o2[read_len] = '\n';
         }
-        o1[read_len] = '\n';
-        o2[read_len] = '\n';
-    }
+    });
     return 0;
 }
 

@@ -1710,7 +1710,7 @@ again:
         if (!lo_open && !hi_open) continue;
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
         KStat<WT> st;
-        if (HAVE_UB && !strict) {
+        if (HAVE_UB && !strict && k < 64) {  // lane_bounds knows nothing about k = 64 (shift amounts stay below 64)
             const int src = k - P.min_mer + lane_base;
             if ((u32) __builtin_amdgcn_readlane((int) M.runs, src) > kHeavyRuns && (sk_k[0] == 0 || sk_k[1] == 0)) {
                 const double ub = readlane_f64(M.ub, src);
@@ -1722,7 +1722,7 @@ again:
                 continue;
             }
         }
-        if (HAVE_UB) {
+        if (HAVE_UB && k < 64) {
             const int src = k - P.min_mer + lane_base;
             // the window masks of this k were computed bit-parallel by lane `src`: fetch them
             // instead of walking the windows (phase A of eval_k)
@@ -2688,11 +2688,12 @@ u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_ld
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len) {
-    // lane_bounds needs every staged segment (< cap) to fit its NW words, and k < 64
+    // lane_bounds needs every staged segment (< cap) to fit its NW words
     const bool wide = P.max_mer > 32;  // 128-bit words, k_mer_check_128 (kmer.cpp:100, 180)
     const u32 lds = exact_lds_bytes(cap, rawwords, wide ? 16u : 8u);
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
-    const int nw = (P.max_mer >= 64 || (P.flags & TREW_FLAG_NO_FILTER)) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
+    // (k = 64 itself has no lane bound -- decide() walks its windows -- but every smaller k of a MAX_MER = 64 run does)
+    const int nw = (P.flags & TREW_FLAG_NO_FILTER) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
     typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
