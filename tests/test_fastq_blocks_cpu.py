@@ -91,3 +91,21 @@ def test_paired_reader_helpers(harness, tmp_path):
             got = [tuple(int(x) for x in line.split()) for line in lines[1:]]
             n = min(len(w1), len(w2))
             assert got == [w1[i] + w2[i] for i in range(n)], (tag, block, per_item)
+
+
+def test_block_chain_under_thread_sanitizer(tmp_path):
+    """The only cross-thread hand-over of the block reader (lines_end / last_nl, published with release, read with
+    acquire) under -fsanitize=thread: 8 threads, 4 KiB blocks, no report and the single-thread answer."""
+    exe = str(tmp_path / "blocks_tsan")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-o", exe,
+                         os.path.join(ROOT, "tests", "harness", "blocks_harness.cpp")], capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("ThreadSanitizer runtime not available: " + cc.stderr[-200:])
+    rnd = random.Random(1)
+    data = "".join("@r%d\n%s\n+\n%s\n" % (i, "A" * n, "I" * n) for i, n in ((i, rnd.choice([0, 36, 150, 400])) for i in range(8000))).encode()
+    path = str(tmp_path / "t.fastq")
+    open(path, "wb").write(data)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    r = subprocess.run([exe, path, "4096", "8"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stderr[-2000:]
+    assert [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()] == reference_rule(data)

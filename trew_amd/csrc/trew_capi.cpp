@@ -29,6 +29,9 @@ struct Slot {
     u32 *d_words = nullptr, *d_offsets = nullptr, *d_lengths = nullptr;  // views into d_buf
     u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
+    int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kMaxSlots * kThrRow)
+    int2 *h_thr = nullptr;   // pinned staging of the same
+    u32 thr_length = 0;      // uniform read length d_thr was computed for (0: none yet)
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
     // ring of (before filter, between, after exact) events: submits may be queued back to back
     // on the slot's stream without a wait in between, each keeps its own timestamps
@@ -216,6 +219,8 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             s.d_lengths = s.d_buf + p.max_batch_reads;
             s.d_words = s.d_buf + 2 * (size_t) p.max_batch_reads;
         }
+        if ((e = hipMalloc((void **) &s.d_thr, kMaxSlots * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
+        if ((e = hipHostMalloc((void **) &s.h_thr, kMaxSlots * kThrRow * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
         if ((e = hipMemset(s.d_wl_count, 0, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMemset", e);
@@ -241,6 +246,8 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     for (auto &s : ctx->slots) {
         if (s.stream) (void) hipStreamSynchronize(s.stream);
         if (s.d_buf) (void) hipFree(s.d_buf);
+        if (s.d_thr) (void) hipFree(s.d_thr);
+        if (s.h_thr) (void) hipHostFree(s.h_thr);
         if (s.d_wl) (void) hipFree(s.d_wl);
         if (s.d_wl_count) (void) hipFree(s.d_wl_count);
         if (s.res.k_high) (void) hipFree(s.res.k_high);
@@ -389,6 +396,22 @@ static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevB
     return 0;
 }
 
+// Thresholds of the prefilter's uniform-geometry path for this batch (nullptr: the batch is ragged).  They depend only
+// on the read length, so a slot recomputes and re-sends its 3 KB table when the length changes; the copy is queued on
+// the slot's stream, in front of the kernel that reads it.
+static int stage_thresholds(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, const int2 **out) {
+    *out = nullptr;
+    if (db.offsets || db.lengths || db.uniform_length == 0) return 0;
+    if (s.thr_length != db.uniform_length) {
+        HIPCHK(ctx, hipStreamSynchronize(s.stream));  // an earlier copy may still be reading the staging buffer
+        fill_thresholds(ctx->dp, db.uniform_length, s.h_thr);
+        HIPCHK(ctx, hipMemcpyAsync(s.d_thr, s.h_thr, kMaxSlots * kThrRow * sizeof(int2), hipMemcpyHostToDevice, s.stream));
+        s.thr_length = db.uniform_length;
+    }
+    *out = s.d_thr;
+    return 0;
+}
+
 extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot) {
     if (!ctx || !batch) return -1;
     if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
@@ -412,10 +435,12 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;        // clean: cleared by the previous launch
     u32 *const wl_count_next = s.d_wl_count + ((s.n_launches + 1) & 1) * kWlCountWords;  // this launch clears it
     s.n_launches++;
+    const int2 *d_thr = nullptr;
+    if (int rc = stage_thresholds(ctx, s, db, &d_thr)) return rc;
     const bool timed = !(ctx->p.flags & TREW_FLAG_NO_TIMING);
     hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
     if (timed) HIPCHK(ctx, hipEventRecord(ev[0], s.stream));
-    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, wl_cap, nullptr, 0, ctx->table.overflow));
+    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, wl_cap, nullptr, 0, ctx->table.overflow, d_thr));
     if (timed) HIPCHK(ctx, hipEventRecord(ev[1], s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
@@ -670,10 +695,15 @@ extern "C" int trew_hip_filter_masks(trew_hip_ctx *ctx, const trew_hip_batch *ba
     const u64 bytes = db.n_units * (u64) slots_per_read * 8ull;
     HIPCHK(ctx, hipMalloc((void **) &d, bytes));
     u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;
+    const int2 *d_thr = nullptr;
+    if (int rc = stage_thresholds(ctx, s, db, &d_thr)) {
+        (void) hipFree(d);
+        return rc;
+    }
     hipError_t e = hipMemsetAsync(d, 0, bytes, s.stream);
     if (e == hipSuccess)
         e = launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, (u32) ctx->p.max_batch_reads, d, slots_per_read,
-                          ctx->table.overflow);
+                          ctx->table.overflow, d_thr);
     if (e == hipSuccess) e = hipMemsetAsync(wl_count, 0, kWlCountBytes, s.stream);  // no exact kernel follows: leave the block clean
     if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
     if (e == hipSuccess) e = hipMemcpy(cand, d, bytes, hipMemcpyDeviceToHost);

@@ -46,6 +46,12 @@ __device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 sh) {
     return __builtin_amdgcn_alignbit(hi, lo, sh);  // ((hi:lo) >> (sh & 31)) & 0xffffffff
 }
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+// popc(x) + acc in one instruction
+__device__ __forceinline__ u32 bcnt_acc(u32 x, u32 acc) {
+    u32 d;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(acc));
+    return d;
+}
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 rfl64(u64 v) {
     u32 lo = __builtin_amdgcn_readfirstlane((u32) v);
@@ -330,7 +336,7 @@ __device__ __forceinline__ u64 filter_segment(const u32 (&lo)[NW], const u32 (&h
 // (every wave64 VALU instruction occupies its SIMD16 for 4 cycles), so instruction count is time.
 // The verdicts of the 64 lanes are kept as wave masks in SGPRs (hasm: lanes that already own a
 // candidate, the return value: lanes passing at this k), so the bookkeeping per k is scalar work.
-// thr_row[k-1] = {ithr, jthr}: (float) m > (float) COUNT * lowf  <=>  m >= ithr = floor((float) COUNT * lowf) + 1,
+// thr_row[k-1] = {ithr, jthr} (kThrRow entries per slot, computed by fill_thresholds): (float) m > (float) COUNT * lowf  <=>  m >= ithr = floor((float) COUNT * lowf) + 1,
 // and bucket 00 = COUNT - t reaches ithr  <=>  t <= jthr = COUNT - ithr.
 template <int NW, int WS, int NWW>
 __device__ __forceinline__ u64 filter_k_uni(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int L, int k,
@@ -352,9 +358,11 @@ __device__ __forceinline__ u64 filter_k_uni(const u32 (&P1)[NW], const u32 (&P2)
             // 3-input bit op below and spends two extra xors per k
             asm volatile("" : "+v"(F1[j]), "+v"(F2[j]));
         }
-        c1x += __popc(F1[j]);
-        cx1 += __popc(F2[j]);
-        c11 += __popc(F1[j] & F2[j]);
+        // v_bcnt_u32_b32 adds its second operand: chaining the words' popcounts costs no separate add (left to itself
+        // the compiler counts three words independently and spends a v_add3 per bucket)
+        c1x = bcnt_acc(F1[j], c1x);
+        cx1 = bcnt_acc(F2[j], cx1);
+        c11 = bcnt_acc(F1[j] & F2[j], c11);
     }
     const u32 c10 = c1x - c11, c01 = cx1 - c11;
     const u32 m3 = max(max(c10, c01), c11);
@@ -399,7 +407,7 @@ struct UniVerdict {
 template <int NW, int WS, int NWW, bool SLOW>
 struct FilterRangeUni {
     static __device__ __forceinline__ void run(const u32 (&P1)[NW], const u32 (&P2)[NW], const u32 (&P3)[NW], int klo, int khi, int L,
-                                               int kmin, int kmax, const int2 *thr_row, bool dbg, UniVerdict &vd) {
+                                               int kmin, int kmax, const int2 *__restrict__ thr_row, bool dbg, UniVerdict &vd) {
         int a = L + 2 - 32 * NWW, b = L + 1 - 32 * (NWW - 1);
         if (NWW == NW) a = klo;
         a = a < klo ? klo : a;
@@ -436,7 +444,7 @@ struct FilterRangeUni<NW, WS, 0, SLOW> {
 // candidate k, vd.clo/chi = the lane's candidate mask when dbg
 template <int NW>
 __device__ __forceinline__ void filter_segment_uni(const u32 (&lo)[NW], const u32 (&hi)[NW], int L, int kmin, int kmax, int gmin, int gmax,
-                                                   const int2 *thr_row, bool dbg, UniVerdict &vd) {
+                                                   const int2 *__restrict__ thr_row, bool dbg, UniVerdict &vd) {
     u32 P1[NW], P2[NW], P3[NW];
     {
         u32 f1[NW], f2[NW], f3[NW];
@@ -481,7 +489,8 @@ constexpr u32 kDefer = 2 * kFilterThreads;                   // units set aside 
 // as the whole k loop.
 template <int NW>
 __global__ __launch_bounds__(kFilterThreads) void filter_kernel(DevParams P, DevBatch B, u32 *wl, u32 *wl_count, u32 wl_cap,
-                                                                u64 *dbg_masks, int dbg_slots, int max_seg, u32 *diag) {
+                                                                u64 *dbg_masks, int dbg_slots, int max_seg, u32 *diag,
+                                                                const int2 *__restrict__ thr_tab) {
     __shared__ u32 stage[kStage];
     __shared__ u32 stage_n, flush_base;
     if (threadIdx.x == 0) stage_n = 0;
@@ -575,24 +584,10 @@ __global__ __launch_bounds__(kFilterThreads) void filter_kernel(DevParams P, Dev
     // a block-full of units is waiting (or the input is exhausted) the general path drains them.
     __shared__ u32 defer[kDefer];
     __shared__ u32 defer_n;
-    __shared__ int2 thr_tab[kMaxSlots][65];  // [k-1]; one entry of padding for the read-ahead
+    // thr_tab[slot * kThrRow + k - 1] = pass thresholds of (slot, k) for this batch's uniform geometry (fill_thresholds, below): read-only
+    // global memory at a wave-uniform address, i.e. scalar loads into SGPRs -- the k loops spend no vector instruction on them
     const u32 UL = B.uniform_length;
-    const bool uni = NW <= 5 && UL != 0 && P.mode != TREW_MODE_LONG && !(P.flags & TREW_FLAG_NO_FILTER);
-    if (uni) {
-        for (u32 i = threadIdx.x; i < (u32) kMaxSlots * 65u; i += blockDim.x) {
-            const int slot = (int) (i / 65u), k = (int) (i % 65u) + 1;
-            const Segment sg = get_segment(P.mode, slot, UL, UL, P.min_mer, P.max_mer, P.slice_len);
-            const int W = (int) sg.len - k + 1;
-            int2 th;
-            th.x = 0x7fffffff;  // nothing passes
-            th.y = -1;
-            if (slot < nslots && sg.valid && W > 0) {
-                th.x = (int) floorf((float) W * P.lowf) + 1;
-                th.y = W - th.x;
-            }
-            thr_tab[slot][k - 1] = th;
-        }
-    }
+    const bool uni = NW <= 5 && UL != 0 && thr_tab != nullptr && P.mode != TREW_MODE_LONG && !(P.flags & TREW_FLAG_NO_FILTER);
     if (threadIdx.x == 0) defer_n = 0;
     __syncthreads();
     u64 base = (u64) blockIdx.x * blockDim.x;
@@ -638,7 +633,7 @@ __global__ __launch_bounds__(kFilterThreads) void filter_kernel(DevParams P, Dev
                             anyn |= nm[j] & lm;
                         }
                         UniVerdict vd;
-                        filter_segment_uni<NW>(lo, hi, (int) sg.len, sg.kmin, sg.kmax, P.min_mer, gmax_run, thr_tab[slot], dbg_masks != nullptr, vd);
+                        filter_segment_uni<NW>(lo, hi, (int) sg.len, sg.kmin, sg.kmax, P.min_mer, gmax_run, thr_tab + slot * kThrRow, dbg_masks != nullptr, vd);
                         dfr = dfr || (active && anyn != 0);
                         any |= (vd.flagm >> lane_id()) & 1ull;
                         if (dbg_masks && active && anyn == 0 && slot < dbg_slots)
@@ -1710,7 +1705,9 @@ again:
         if (!lo_open && !hi_open) continue;
         const double need = lo_open ? (hi_open ? (thr_lo < thr_hi ? thr_lo : thr_hi) : thr_lo) : thr_hi;
         KStat<WT> st;
-        if (HAVE_UB && !strict && k < 64) {  // lane_bounds knows nothing about k = 64 (shift amounts stay below 64)
+        // lane_bounds knows nothing about k = 64 (shift amounts stay below 64); only the 128-bit-word kernels can meet it
+        constexpr bool kMay64 = sizeof(WT) > 8;
+        if (HAVE_UB && !strict && (!kMay64 || k < 64)) {
             const int src = k - P.min_mer + lane_base;
             if ((u32) __builtin_amdgcn_readlane((int) M.runs, src) > kHeavyRuns && (sk_k[0] == 0 || sk_k[1] == 0)) {
                 const double ub = readlane_f64(M.ub, src);
@@ -1722,7 +1719,7 @@ again:
                 continue;
             }
         }
-        if (HAVE_UB && k < 64) {
+        if (HAVE_UB && (!kMay64 || k < 64)) {
             const int src = k - P.min_mer + lane_base;
             // the window masks of this k were computed bit-parallel by lane `src`: fetch them
             // instead of walking the windows (phase A of eval_k)
@@ -2656,12 +2653,33 @@ int pick_nw(u32 max_seg_len) {
     return 32;
 }
 
+// Pass thresholds of the uniform-geometry fast path for one batch geometry: table[slot * kThrRow + k - 1] = {ithr, jthr}.
+// Host side (single-precision multiply, the same IEEE operation the general path performs on the device).
+void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
+    const int nslots = mode_slots(P.mode);
+    for (int slot = 0; slot < kMaxSlots; slot++) {
+        const Segment sg = get_segment(P.mode, slot, uniform_length, uniform_length, P.min_mer, P.max_mer, P.slice_len);
+        for (int k = 1; k <= kThrRow; k++) {
+            const int W = (int) sg.len - k + 1;
+            int2 th;
+            th.x = 0x7fffffff;  // nothing passes
+            th.y = -1;
+            if (slot < nslots && sg.valid && W > 0) {
+                const volatile float prod = (float) W * P.lowf;  // volatile: no contraction, no extended precision
+                th.x = (int) floorf(prod) + 1;
+                th.y = W - th.x;
+            }
+            table[slot * kThrRow + k - 1] = th;
+        }
+    }
+}
+
 hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevParams &P, const DevBatch &B, u32 *wl, u32 *wl_count,
-                         u32 wl_cap, u64 *dbg_masks, int dbg_slots, u32 *diag) {
+                         u32 wl_cap, u64 *dbg_masks, int dbg_slots, u32 *diag, const int2 *d_thr) {
     const int nw = pick_nw(max_seg_len);
     const int max_seg = (int) std::min<u32>(max_seg_len, (u32) (32 * nw - 1));
     if (B.n_units == 0) return hipSuccess;
-    typedef void (*kern_t)(DevParams, DevBatch, u32 *, u32 *, u32, u64 *, int, int, u32 *);
+    typedef void (*kern_t)(DevParams, DevBatch, u32 *, u32 *, u32, u64 *, int, int, u32 *, const int2 *);
     const kern_t fn = nw == 3 ? filter_kernel<3> : nw == 5 ? filter_kernel<5> : nw == 10 ? filter_kernel<10> : filter_kernel<32>;
     const u32 threads = kFilterThreads;
     // Persistent blocks with a static, grid-strided share of the reads each; twice the resident number of blocks
@@ -2679,7 +2697,7 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
     u64 blocks = (B.n_units + threads - 1) / threads;
     const u64 persistent = (u64) n_cu * (u64) per_cu;
     if (blocks > persistent) blocks = persistent;
-    hipLaunchKernelGGL(fn, dim3((u32) blocks), dim3(threads), 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg, diag);
+    hipLaunchKernelGGL(fn, dim3((u32) blocks), dim3(threads), 0, st, P, B, wl, wl_count, wl_cap, dbg_masks, dbg_slots, max_seg, diag, d_thr);
     return hipGetLastError();
 }
 
