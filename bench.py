@@ -121,7 +121,7 @@ class Workload:
         dev_mode = {"short": T.MODE_SHORT, "pair": T.MODE_PAIR, "long": T.MODE_LONG}[mode]
         self.n_reads_dev = 2 * n if mode == "pair" else n  # n counts pairs in pair mode
         self.t = t = T.TrewHip(mode=dev_mode, min_mer=args.min_mer, max_mer=args.max_mer, device=dev_index, n_slots=max(1, args.streams),
-                               max_batch_words=16, max_batch_reads=self.n_reads_dev, table_log2_slots=20, flags=args.flags)
+                               max_batch_words=16, max_batch_reads=self.n_reads_dev, table_log2_slots=22, flags=args.flags)
         stride = 3 * ((L + 31) // 32)
         self.to_free = []
         if mode == "short":
