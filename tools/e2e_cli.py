@@ -39,6 +39,23 @@ for t in (8, 16):
                             "-t", str(t), "--stats", *extra], capture_output=True, text=True)
         print("pairs threads", t, " ".join(extra), " | ".join(x for x in r.stderr.strip().splitlines() if x.startswith("[trew]")) if r.stderr else r.returncode)
 
+# long reads (config 4's shape): 150 k ONT-like reads, ~2.3 Gbases, 4.7 GB of FASTQ text
+nlong = 150_000
+lb, lst, lnd = capi.synth_long_ascii(20250218, 0, nlong)
+with open("/tmp/e2e_long.fastq", "wb") as f:
+    mv = memoryview(lb)
+    for i in range(nlong):
+        seq = mv[int(lst[i]): int(lnd[i]) + 1]
+        f.write(b"@r\n")
+        f.write(seq)
+        f.write(b"\n+\n")
+        f.write(b"I" * len(seq))
+        f.write(b"\n")
+del lb
+for t in (8, 16):
+    r = subprocess.run([os.path.join(root, "trew_amd/bin/trew"), "long", "5", "32", "/tmp/e2e_long.fastq", "-t", str(t), "--stats"], capture_output=True, text=True)
+    print("long threads", t, " | ".join(x for x in r.stderr.strip().splitlines() if x.startswith("[trew]")) if r.stderr else r.returncode)
+
 # the same file as plain gzip (one member: gzread on one thread, as the reference does) and as BGZF
 # (independent 64 KiB members: inflated on several threads by host/bgzf_reader.hpp)
 import gzip, zlib, struct
