@@ -378,7 +378,7 @@ def main():
             "flagged_reads_per_step": m["nflag"],
             "reads_per_s": round(world * n * args.steps / dt, 1),
             "host_ms_per_step": round(m["host_ms"], 4),
-            "table_rows": int(len(m["rows"])),
+            "table_rows": int(len(m["rows"])) if m["rows"] is not None else None,
         }
 
     # CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1 only)

@@ -172,7 +172,7 @@ def allreduce_rows_into_table(ctx, rows, device="cpu", group=None):
     return ctx.collect_rows()
 
 
-def allreduce_table_device(ctx, device, group=None, force_collectives=False):
+def allreduce_table_device(ctx, device, group=None, force_collectives=False, rows_on_every_rank=False):
     """The reduction bench.py uses for N > 1 with backend "nccl" (= RCCL): nothing leaves HBM until the final rows.
 
       1. trew_hip_collect_device compacts this rank's table into a device tensor (32 B per row: table, k, word, count);
@@ -182,7 +182,8 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False):
       4. trew_hip_collect returns the merged rows; every rank's table now holds the global sums.
 
     ctx: trew_amd.capi.TrewHip.  device: the torch device of ctx's GPU.  force_collectives issues the two
-    all_gathers even at world size 1 (the one-GPU test of the RCCL path)."""
+    all_gathers even at world size 1 (the one-GPU test of the RCCL path).  Returns the merged rows on rank 0
+    (on every rank with rows_on_every_rank), None elsewhere."""
     from .capi import ROW_DTYPE
 
     on = dist.is_available() and dist.is_initialized()
@@ -212,7 +213,10 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False):
     for r in range(world):
         if r != rank and sizes[r]:
             ctx.add_rows_device(gathered[r * n_max:].data_ptr(), sizes[r])
-    return ctx.collect_rows()
+    if rows_on_every_rank or rank == 0:
+        ctx._collect_cap = max(getattr(ctx, "_collect_cap", 0), sum(sizes) + 1024)  # the merged table holds at most this many rows: one compaction
+        return ctx.collect_rows()
+    return None  # this rank's device table holds the global sums as well; only rank 0 needs them on the host
 
 
 def shard_range(n_total, rank, world):
