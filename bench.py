@@ -36,7 +36,6 @@ CLOCK_HZ = 2.4e9
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9
 EVALS_PER_150BP_READ = 3220  # (window,k) evaluations per 150-bp read at 5 32
 CONFIG5_READS_PER_GPU = 1_000_000_000 // 8  # BASELINE config 5: 1 B reads over 8 GPUs
-PROFILE_ROUNDS = ("r02", "r01")  # newest committed rocprofv3 summaries first
 
 
 def usable_cores():
