@@ -281,6 +281,16 @@ def test_empty_and_tiny_batches():
     with pytest.raises(T.TrewHipError):
         with T.TrewHip(mode=T.MODE_SHORT) as t:
             t.submit_reads([b"A" * 1001])
+    # a batch whose reads point outside its words is refused on the host: the kernels index words[] with these numbers
+    words, offs, lens = capi.pack_reads([b"ACGT" * 30, b"TTAGGG" * 20])
+    for bad_offs, bad_lens in ((offs + np.uint32(len(words)), lens), (offs, lens + np.uint32(4000))):
+        with T.TrewHip(mode=T.MODE_LONG if bad_lens is not lens else T.MODE_SHORT) as t:
+            with pytest.raises(T.TrewHipError):
+                t.submit(t.host_batch(words, bad_offs, bad_lens))
+    with T.TrewHip(mode=T.MODE_SHORT) as t:
+        w = np.zeros(60, dtype=np.uint32)
+        with pytest.raises(T.TrewHipError):
+            t.submit(capi.Batch(w.ctypes.data, len(w), None, None, 150, 15, 5, 0, 150))  # 5 reads x 15 words > 60 words
 
 
 # ---------------------------------------------------------------- paired-end (buffer_task_pair)

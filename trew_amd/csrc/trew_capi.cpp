@@ -366,6 +366,13 @@ static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevB
         db->lengths = b->lengths;
     } else {
         if (b->n_words > ctx->p.max_batch_words) return fail(ctx, "batch has more words than max_batch_words");
+        if (b->offsets) {
+            // the kernels index words[] with these: a read that points outside the batch must never reach the device
+            for (u64 i = 0; i < b->n_reads; i++)
+                if ((u64) b->offsets[i] + 3ull * (((u64) b->lengths[i] + 31ull) / 32ull) > b->n_words) return fail(ctx, "a read's offset / length points outside the batch's words");
+        } else if (b->n_reads && (b->n_reads - 1) * (u64) b->uniform_stride + 3ull * (((u64) b->uniform_length + 31ull) / 32ull) > b->n_words) {
+            return fail(ctx, "uniform batch: n_reads * stride exceeds the batch's words");
+        }
         // The caller laid the three arrays out back to back in one buffer (see trew_hip.h): ONE copy.  A host that
         // submits thousands of batches a second is bound by HIP API calls, not by bytes.
         if (b->offsets && b->lengths == b->offsets + b->n_reads && b->words == b->lengths + b->n_reads) {  // [offsets][lengths][words]
