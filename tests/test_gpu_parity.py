@@ -271,6 +271,23 @@ def test_one_copy_batches_and_untimed_contexts():
                 assert a > 0 and b > 0 and 0 < nflag <= 700
 
 
+def test_filter_masks_between_submits_leaves_the_queue_counters_clean():
+    """trew_hip_filter_masks runs the prefilter alone on slot 0's stream and counter block; submits before and after it
+    (whose exact kernels clear each other's counter blocks, no memset in between) must be unaffected."""
+    buf, st, nd = capi.synth_short_ascii(6, 0, 9000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, n_slots=1, max_batch_reads=4096, max_batch_words=1 << 18) as t:
+        for i in range(0, 9000, 3000):
+            t.submit_reads(reads[i:i + 3000], 0)
+            t.wait(0)
+            cand = t.filter_masks(t.host_batch(*capi.pack_reads(reads[i:i + 3000])), 3)
+            assert np.count_nonzero(cand.any(axis=1)) >= t.last_timing(0)[2] > 0  # the masks are per segment, flagging per read
+            cand2 = t.filter_masks(t.host_batch(*capi.pack_reads(reads[:500])), 3)  # twice in a row
+            assert cand2.shape == (500, 3)
+        assert t.collect() == want
+
+
 def test_empty_and_tiny_batches():
     with T.TrewHip(mode=T.MODE_SHORT) as t:
         t.submit_reads([])
