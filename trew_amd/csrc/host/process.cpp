@@ -126,6 +126,12 @@ struct Chunk {
     char *buffer1 = nullptr, *buffer2 = nullptr;
     std::vector<int64_t> st1, nd1, st2, nd2;
     bool sentinel = false;
+    // single-file chunks leave the reader with their lines only COUNTED (the reader is the serial part of a compressed
+    // run: it inflates, counts newlines and carries a split sequence line over); the consumer that gets the chunk finds
+    // the sequence lines itself from `total` bytes and the number of newlines that precede the chunk in the file
+    bool located = true;
+    int total = 0;
+    int64_t num_before = 0;
 };
 
 class ChunkQueue {  // the role of tbb::concurrent_bounded_queue (kmer.h:111-112)
@@ -327,6 +333,23 @@ static void worker_loop(Scanner *s, Worker *w, ChunkQueue *q) {
             delete ch;
             break;
         }
+        if (!ch->located) {
+            // the newline that makes num & 3 == 2 closes a sequence line (read_fastq_thread, kmer.cpp:1002-1011); a chunk
+            // starts at a line start or, after a carry-over, at the start of a sequence line
+            if (w->nl.size() < (size_t) LENGTH) w->nl.resize((size_t) LENGTH);
+            const size_t cnt = scan_newlines(ch->buffer1, (size_t) ch->total, w->nl.data());
+            const bool long_mode = s->mode == TREW_MODE_LONG;
+            for (size_t j = (size_t) ((1 - ch->num_before) & 3); j < cnt; j += 4) {
+                const int64_t start = j > 0 ? (int64_t) w->nl[j - 1] + 1 : 0, len = (int64_t) w->nl[j] - start;
+                if (long_mode) {
+                    if (len < s->cfg.SLICE_LENGTH) continue;  // kmer.cpp:1184
+                } else if (len > MAX_SEQ) {
+                    die("This mode is designed for short-read sequencing. Please use 'trew long'.");  // kmer.cpp:1006-1009
+                }
+                ch->st1.push_back(start);
+                ch->nd1.push_back(start + len - 1);
+            }
+        }
         if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffers are free again
         uint64_t nw, n_reads;
         if (s->mode == TREW_MODE_PAIR) {
@@ -352,34 +375,23 @@ static char *alloc_buffer() {
     return b;
 }
 
-// read_fastq_thread (kmer.cpp:987-1038) and read_fastq_long_thread (1166-1213)
-static void read_fastq_thread(FileReader &fr, ChunkQueue *q, bool long_mode, int slice_length) {
-    int num = 0, shift = 0, idx = -1;
+// read_fastq_thread (kmer.cpp:987-1038) and read_fastq_long_thread (1166-1213): 4 MiB chunks, sequence lines by counting
+// newlines, a sequence line split across two chunks carried over.  This thread is the serial part of a compressed run, so it
+// only COUNTS the newlines of a chunk (AVX2) and leaves finding the lines to the consumer (Chunk::located).
+static void read_fastq_thread(FileReader &fr, ChunkQueue *q) {
+    int64_t num = 0;
+    int shift = 0;
     char *buffer = alloc_buffer();
     for (;;) {
         Chunk *ch = new Chunk();
         const int bytes_read = fr.read(buffer + shift, LENGTH - 1 - shift);
         const int total = (bytes_read > 0 ? bytes_read : 0) + shift;
         buffer[total] = '\0';
-        for (const char *nl = (const char *) memchr(buffer, '\n', (size_t) total); nl; nl = (const char *) memchr(nl + 1, '\n', (size_t) (buffer + total - nl - 1))) {
-            const int i = (int) (nl - buffer);
-            num += 1;
-            if ((num & 3) == 2) {
-                const int len = (i - 1) - (idx + 1) + 1;
-                if (long_mode) {
-                    if (len >= slice_length) {  // kmer.cpp:1184
-                        ch->st1.push_back(idx + 1);
-                        ch->nd1.push_back(i - 1);
-                    }
-                } else {
-                    if (len > MAX_SEQ) die("This mode is designed for short-read sequencing. Please use 'trew long'.");  // kmer.cpp:1006-1009
-                    ch->st1.push_back(idx + 1);
-                    ch->nd1.push_back(i - 1);
-                }
-            }
-            idx = i;
-        }
         ch->buffer1 = buffer;
+        ch->located = false;
+        ch->total = total;
+        ch->num_before = num;
+        num += (int64_t) count_newlines(buffer, (size_t) total);
         if (bytes_read <= 0) {
             q->push(ch);
             if (fr.eof()) break;
@@ -389,15 +401,14 @@ static void read_fastq_thread(FileReader &fr, ChunkQueue *q, bool long_mode, int
             _exit(EXIT_FAILURE);
         }
         char *buffer_new = alloc_buffer();
+        shift = 0;
         if ((num & 3) == 1) {  // inside a sequence line: carry it over (kmer.cpp:1026-1029)
+            const char *last = (const char *) memrchr(buffer, '\n', (size_t) total);
+            const int idx = last ? (int) (last - buffer) : -1;
             const int rest = total - idx - 1;
             memcpy(buffer_new, buffer + idx + 1, (size_t) rest);
             shift = rest;
-            idx = -1;
             if (shift >= LENGTH - 2) die("a read does not fit one 4 MiB chunk");
-        } else {
-            shift = 0;
-            idx = -1;  // positions restart in the new buffer
         }
         q->push(ch);
         buffer = buffer_new;
@@ -771,7 +782,7 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
             read_pair_fastq_thread(f1, f2, &q);
             f2.close();
         } else {
-            read_fastq_thread(f1, &q, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
+            read_fastq_thread(f1, &q);
         }
         f1.close();
         for (size_t i = 0; i < s->workers.size(); i++) {  // sentinels, kmer.cpp:1304-1310
