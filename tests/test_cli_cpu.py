@@ -33,6 +33,10 @@ def run(*args):
         (["short", "5", "32", "--paired_end", "--fq1", FQ], "--fq1 and --fq2 are required in paired-end mode."),
         (["short", "5", "32", "--paired_end", "--fq1", FQ, FQ, "--fq2", FQ], "--fq1 and --fq2 must have the same number of files."),
         (["short", "5", "32", "/nonexistent.fastq"], "/nonexistent.fastq : file not found"),
+        # options of this build (stderr only; stdout stays the reference's CSV)
+        (["short", "5", "32", FQ, "--table_log2_slots", "5"], "table_log2_slots must be in range 12 to 30."),
+        (["short", "5", "32", FQ, "--batch_mib", "0"], "Usage: short"),
+        (["short", "5", "32", FQ, "--devices", "0,x"], "Usage: short"),
     ],
 )
 def test_argument_errors(args, msg):
