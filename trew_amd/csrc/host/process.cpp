@@ -169,7 +169,7 @@ struct Worker {
     std::vector<uint32_t> tmp_off, tmp_len;  // block reader: offsets / lengths until the batch is closed
     uint64_t words_cap = 0, reads_cap = 0;
     uint64_t reads = 0, bases = 0, submits = 0;
-    double t_scan = 0, t_wait = 0, t_pack = 0, t_submit = 0;  // seconds per phase, for --stats
+    double t_scan = 0, t_wait = 0, t_pack = 0, t_submit = 0, t_pressure = 0;  // seconds per phase, for --stats (t_pressure is part of t_submit)
     std::vector<int64_t> st, nd;      // block-parallel reader: sequence lines of the current block
     std::vector<uint32_t> nl;         // newline offsets of the current block
 };
@@ -305,7 +305,10 @@ static void submit_packed(Scanner *s, Worker *w, uint32_t *h_words, uint32_t *h_
     // into host memory before this batch adds to it.  Counts can only be lost if one batch fills what is left of the
     // table AND the spill log (>= 64 k rows, 1 M at the default table size); trew_hip_collect reports that as an error.
     w->submits++;
-    if (under_pressure(c)) {
+    const auto tp0 = std::chrono::steady_clock::now();
+    const bool pressed = under_pressure(c);
+    w->t_pressure += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+    if (pressed) {
         std::unique_lock<std::shared_mutex> lk(d->drain_mu);  // waits for running submits, blocks new ones
         if (under_pressure(c)) {                              // nobody drained in the meantime
             drain_device(s, d);
@@ -758,7 +761,8 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
     for (auto &w : s->workers) {
         w.reads = 0;
         w.bases = 0;
-        w.t_scan = w.t_wait = w.t_pack = w.t_submit = 0;
+        w.t_scan = w.t_wait = w.t_pack = w.t_submit = w.t_pressure = 0;
+        w.submits = 0;
     }
     const uint64_t drains0 = s->drains;
     bool done = false;
@@ -804,11 +808,14 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
                 name1, (unsigned long long) s->stats.reads, (unsigned long long) s->stats.bases, s->stats.seconds,
                 s->stats.bases / s->stats.seconds / 1e9, how, (int) s->workers.size(), (unsigned long long) (s->drains - drains0));
     if (cfg.stats && done) {
-        double a = 0, b = 0, c = 0, d = 0;
-        for (auto &w : s->workers) a += w.t_scan, b += w.t_wait, c += w.t_pack, d += w.t_submit;
+        double a = 0, b = 0, c = 0, d = 0, e = 0;
+        uint64_t nsub = 0;
+        for (auto &w : s->workers) a += w.t_scan, b += w.t_wait, c += w.t_pack, d += w.t_submit, e += w.t_pressure, nsub += w.submits;
         const double n = (double) s->workers.size();
-        fprintf(stderr, "[trew]   per worker (mean seconds): newline scan + line chain %.3f, wait for the slot %.3f, pack %.3f, submit %.3f\n", a / n, b / n,
-                c / n, d / n);
+        fprintf(stderr,
+                "[trew]   per worker (mean seconds): newline scan + line chain %.3f, wait for the slot %.3f, pack %.3f, submit %.3f (of which table "
+                "pressure query %.3f); %llu batches\n",
+                a / n, b / n, c / n, d / n, e / n, (unsigned long long) nsub);
     }
     return process_output(name1, r, cfg.MIN_MER, stdout);  // pair mode prints file 1 only (kmer.cpp:1409)
 }
