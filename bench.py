@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--mode", default="short", choices=["short", "pair", "long"],
                     help="short = the BASELINE metric (config 2); pair / long = configs 3 / 4 as the primary line")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "device", "host"],
+                    help="table reduction: device = collect_device -> all_gather of device tensors -> add_rows_device (what nccl runs use); "
+                         "host = the same exchange with host-side row arrays; auto = device with nccl, host otherwise")
     args = ap.parse_args()
 
     import torch
@@ -291,8 +294,8 @@ def main():
     def reduce_fn(t, rows):
         if world == 1:
             return rows
-        if args.backend == "nccl":
-            return allreduce_table_device(t, dev)  # compaction -> RCCL all_gather -> add into the device table, all in HBM
+        if args.exchange == "device" or (args.exchange == "auto" and args.backend == "nccl"):
+            return allreduce_table_device(t, dev)  # compaction -> all_gather of device tensors (RCCL) -> add into the device table, all in HBM
         return allreduce_rows_into_table(t, t.collect_rows(), device=torch.device("cpu"))
 
     w = Workload(T, capi, args.mode, n, L, args, dev.index, rank * n)  # contiguous read-index ranges per rank

@@ -73,9 +73,21 @@ def test_bench_two_ranks_one_gpu_gloo_rehearsal():
     port = 29950 + os.getpid() % 40
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--backend", "gloo", "--reads", "2000000"]
+           "--backend", "gloo", "--exchange", "device", "--reads", "2000000"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["table_rows"] > 1000
+
+
+def test_two_ranks_device_tensor_exchange_against_the_oracle():
+    """allreduce_table_device (collect_device -> all_gather of device tensors -> add_rows_device), the reduction of the nccl
+    runs, with two real ranks: gloo moves the device tensors, both ranks share this GPU.  Merged tables = oracle on all reads."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29900 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "harness", "two_rank_exchange.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "TWO_RANK_EXCHANGE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
