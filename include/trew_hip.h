@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TREW_HIP_ABI_VERSION 2
+#define TREW_HIP_ABI_VERSION 3
 
 /* scan modes: which per-read driver of the reference is reproduced */
 enum {
@@ -55,6 +55,8 @@ enum {
     TREW_FLAG_DEBUG_NO_EMIT = 2, /* timing experiments only: drop every table update (results are empty) */
     TREW_FLAG_DEBUG_NO_KLOOP = 4, /* timing experiments only: prefilter without its k loop (nothing is flagged) */
     TREW_FLAG_DEBUG_POISON_LDS = 32, /* tests: the exact kernel starts from garbage-filled LDS */
+    TREW_FLAG_DEBUG_WIDE_NO_WAIT = 128, /* tests: the wide table (k > 32) never waits for a claimed slot's ready bit -- every such
+                                  wait counts as timed out (trew_hip_debug_counters), duplicates are left for collect to merge */
     TREW_FLAG_NO_TIMING = 64 /* no HIP events around the kernels (trew_hip_last_timing is unavailable): for hosts that
                                 submit ~10^4 small batches a second and are bound by API calls */
 };
@@ -146,6 +148,18 @@ int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, uint64_t n_ro
 int trew_hip_collect_device(trew_hip_ctx *ctx, trew_hip_row *d_rows, uint64_t cap, uint64_t *n_rows);
 int trew_hip_add_rows_device(trew_hip_ctx *ctx, const trew_hip_row *d_rows, uint64_t n_rows);
 int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src);
+/* The whole exchange behind ONE collective (ABI 3).  Every rank owns one slice of 1 + slice_rows rows of a gather
+ * buffer: row 0 is the slice's header (count = number of rows the rank has, everything else 0), rows 1.. are what
+ * trew_hip_collect_device wrote.  After a single all_gather of the slices, d_buf holds n_slices of them and this call
+ * adds the rows of every slice but own_slice into the context's tables with one kernel over the whole buffer
+ * (preceded by a validation pass on the same stream: a row out of range fails the call and NOTHING is added).
+ * producer_stream: the HIP stream (hipStream_t) the collective ran on -- the kernels are ordered behind it on the
+ * device, no host synchronisation in between; NULL = wait for the whole device first.
+ * *max_rows receives the largest header count.  If it exceeds slice_rows some rank's rows did not fit: nothing was
+ * added anywhere (every rank sees the same headers), the call returns 0 and the caller repeats the exchange with
+ * larger slices.  Matches the thread merge of process_output, kmer.cpp:1486-1515 (sums over contributors). */
+int trew_hip_add_gathered_device(trew_hip_ctx *ctx, const trew_hip_row *d_buf, uint32_t n_slices, uint32_t own_slice,
+                                 uint64_t slice_rows, void *producer_stream, uint64_t *max_rows);
 
 /* Fill state of the device tables (a snapshot; does not wait for running batches).  The reference's hash maps
  * grow without bound (absl::flat_hash_map, kmer.h:79); the device table has a fixed number of slots, rows that
@@ -155,6 +169,16 @@ int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src);
  * Any pointer may be NULL. */
 int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *total_slots, uint64_t *spilled_rows,
                             uint64_t *spill_capacity);
+
+/* How often the kernels took their rare fall-back paths since the last trew_hip_reset_tables (waits for every slot).
+ * Diagnostic: tests assert that each path is live code and that results still equal the oracle when it runs.
+ * (The three fall-back counters are kept per DEVICE: contexts that share a GPU share them.)
+ * out[0] decide(): speculative skip refused, segment decided again with every k counted
+ * out[1] eval_runs(): more than 64 runs of adjacent same-class windows, classes counted window by window
+ * out[2] wide table (k > 32): gave up waiting for a slot's ready bit (collect merges the duplicate slot this can leave)
+ * out[3] keys inserted into the narrow table, out[4] into the wide table.   n <= TREW_DEBUG_COUNTERS entries are written. */
+#define TREW_DEBUG_COUNTERS 5
+int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n);
 
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for
  * TREW_MODE_SEGMENT the (k_high, k_low, MAX_SEQ at k_high, MAX_SEQ at k_low)

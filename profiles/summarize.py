@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("suffix")
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--traffic", action="store_true")
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--read-len", type=int, default=150)
@@ -32,10 +32,13 @@ def main():
     ks = glob.glob(os.path.join(base, "trace", "*", "*_kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, "kernel_stats_%s.csv" % a.suffix))
+    ks = glob.glob(os.path.join(base, "trace_serial", "*", "*_kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, "kernel_stats_%s_serial.csv" % a.suffix))
     summary = {}
     with open(os.path.join(out, "pmc_summary_%s.csv" % a.suffix), "w") as f:
         f.write("kernel,counter,dispatches,avg_per_dispatch\n")
-        for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3"):
             fs = glob.glob(os.path.join(base, d, "*", "*_counter_collection.csv"))
             if not fs:
                 continue

@@ -225,6 +225,12 @@ def test_cli_tiny_table_is_drained_not_lost(tmp_path):
         drains = int(r.stderr.split(" table drain(s)")[0].split()[-1])
         assert drains >= 1, r.stderr
     assert run("short", "5", "32", a) == want  # default table: same output, no drain needed
+    # several contexts: each is kept at or below half full during the file, but their UNION does not fit device 0 --
+    # the final reduction (trew_hip_merge into device 0) must drain device 0 between merges instead of overflowing it
+    r = subprocess.run([TREW, "short", "5", "32", a, "--table_log2_slots", "12", "--devices", "0,0,0", "-t", "4", "--batch_mib", "1", "--stats"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == want
 
 
 def test_cli_several_contexts_reduce_on_the_device(tmp_path):

@@ -631,6 +631,54 @@ def test_full_size_properties_config2():
     assert got == want
 
 
+def test_full_size_config5_share():
+    """BASELINE config 5 as far as one GPU goes: the per-GPU share of "1 B reads over 8 GPUs" -- 125 M reads of 150 bp
+    (7.5 GB of packed reads) -- generated at the read offset of the LAST rank (first_read = 875 000 000, what
+    shard_range(10**9, 7, 8) gives), so that 64-bit read indices, the counter-based generator far from zero and a batch
+    of this size are all exercised:
+      * idempotence (a second pass doubles every count);
+      * sharding invariance: five 25 M sub-batches alternating over two slots (two streams, overlapping kernels) give the
+        tables of the one 125 M batch;
+      * the first 200 k reads of that range are bit-exact against the CPU oracle fed the SAME range from the host generator.
+    The exchange between ranks at such offsets: test_gpu_rccl.py::test_two_ranks_at_config5_offsets."""
+    from trew_amd.dist import shard_range
+
+    n_total, world, L = 1_000_000_000, 8, 150
+    lo, hi = shard_range(n_total, 7, world)
+    assert (lo, hi) == (875_000_000, 1_000_000_000)
+    n = hi - lo
+    stride = 3 * ((L + 31) // 32)
+    seed = 20250218
+    with T.TrewHip(mode=T.MODE_SHORT, n_slots=2, max_batch_reads=n, max_batch_words=16, table_log2_slots=22) as t:
+        d = t.malloc(n * stride * 4 + 64)
+        t.synth_short_device(seed, lo, n, L, d)
+        t.submit(t.device_uniform_batch(d, n, L))
+        t.wait()
+        whole = t.collect()
+        assert sum(sum(v.values()) for v in whole.values()) > 125_000_000
+        t.submit(t.device_uniform_batch(d, n, L), 1)
+        t.wait(1)
+        assert t.collect() == {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        t.reset_tables()
+        q = n // 5
+        for i in range(5):
+            t.submit(t.device_uniform_batch(d + i * q * stride * 4, q, L), i & 1)
+        t.wait(0)
+        t.wait(1)
+        assert t.collect() == whole
+        k = 200_000
+        t.reset_tables()
+        t.submit(t.device_uniform_batch(d, k, L))
+        t.wait()
+        got = t.collect()
+        t.free(d)
+    buf, st, nd = capi.synth_short_ascii(seed, lo, k, L)
+    want, _ = O.run_short_mt_timed(O.OracleParams(), buf, st, nd, os.cpu_count() or 8)
+    assert got == want
+    buf0, _, _ = capi.synth_short_ascii(seed, 0, 64, L)
+    assert bytes(buf[:64 * (L + 1)]) != bytes(buf0[:64 * (L + 1)])  # the offset really selects other reads
+
+
 def test_full_size_config3_pairs():
     """BASELINE config 3 at full size (50 M pairs of 2 x 150 bp, device-generated, 6 GB of packed reads):
     sharding invariance of the tables, and bit-exactness against the CPU oracle on a 30 k-pair prefix
@@ -827,13 +875,126 @@ def test_table_reduction_entry_points():
         assert capi.rows_to_tables(got_rows) == part_b
         a.add_rows_device(d_rows, n)
         assert a.collect() == want
-        # a row that cannot be a table row is refused loudly
-        bad = np.zeros(1, dtype=capi.ROW_DTYPE)
-        bad["k"], bad["table"], bad["count"] = 99, 0, 1
-        a._chk(a.lib.trew_hip_memcpy_h2d(a.ctx, d_rows, bad.ctypes.data, row_bytes), "h2d")
-        with pytest.raises(T.TrewHipError):
-            a.add_rows_device(d_rows, 1)
+        # a row that cannot be a table row is refused loudly, and the add is all or nothing: the valid rows that travel
+        # with the bad one are NOT added, and the context stays usable (no sticky error)
+        mixed = got_rows.copy()
+        mixed["k"][n // 2] = 99
+        a._chk(a.lib.trew_hip_memcpy_h2d(a.ctx, d_rows, mixed.ctypes.data, n * row_bytes), "h2d")
+        with pytest.raises(T.TrewHipError, match="nothing was added"):
+            a.add_rows_device(d_rows, n)
+        assert a.collect() == want
+        a._chk(a.lib.trew_hip_memcpy_h2d(a.ctx, d_rows, got_rows.ctypes.data, n * row_bytes), "h2d")
+        a.add_rows_device(d_rows, n)  # the same buffer without the bad row: accepted
+        assert a.collect() == _tables_sum(want, part_b)
         a.free(d_rows)
+
+
+def test_gathered_exchange_buffer():
+    """trew_hip_add_gathered_device: the one-kernel merge behind the single all_gather of the cross-GPU exchange.  Three
+    contexts stand in for three ranks; the gather buffer is assembled by hand (what the collective would deliver)."""
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 45000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(), reads)
+    third = len(reads) // 3
+    row_bytes = capi.ROW_DTYPE.itemsize
+    ctxs = [T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=third + 8, max_batch_words=1 << 22) for _ in range(3)]
+    try:
+        for i, c in enumerate(ctxs):
+            c.submit_reads(reads[i * third:(i + 1) * third])
+            c.wait()
+        parts = [c.collect() for c in ctxs]
+        n_rows = [sum(len(v) for v in p.values()) for p in parts]
+        for cap in (max(n_rows) + 5, max(n_rows)):  # with room to spare, and exactly full
+            gathered = ctxs[0].malloc(3 * (1 + cap) * row_bytes)
+            hdr = np.zeros(1, dtype=capi.ROW_DTYPE)
+            for i, c in enumerate(ctxs):
+                base = gathered + i * (1 + cap) * row_bytes
+                assert c.collect_device(base + row_bytes, cap) == n_rows[i]
+                hdr["count"] = n_rows[i]
+                c._chk(c.lib.trew_hip_memcpy_h2d(c.ctx, base, hdr.ctypes.data, row_bytes), "h2d")
+            for i, c in enumerate(ctxs):
+                assert c.add_gathered_device(gathered, 3, i, cap) == max(n_rows)
+                assert c.collect() == want  # every "rank" now holds the global sums
+                c.reset_tables()
+                c.add_rows(parts[i])
+            ctxs[0].free(gathered)
+        # a slice too small for one rank's rows: every rank sees the header, nothing is added anywhere, the count comes back
+        cap = min(n_rows) - 1
+        gathered = ctxs[0].malloc(3 * (1 + cap) * row_bytes)
+        for i, c in enumerate(ctxs):
+            base = gathered + i * (1 + cap) * row_bytes
+            assert c.collect_device(base + row_bytes, cap) == n_rows[i]
+            hdr["count"] = n_rows[i]
+            c._chk(c.lib.trew_hip_memcpy_h2d(c.ctx, base, hdr.ctypes.data, row_bytes), "h2d")
+        assert ctxs[1].add_gathered_device(gathered, 3, 1, cap) == max(n_rows) > cap
+        assert ctxs[1].collect() == parts[1]
+        # a row out of range in a peer's slice: refused, nothing added, context still usable
+        cap = max(n_rows)
+        ctxs[0].free(gathered)
+        gathered = ctxs[0].malloc(3 * (1 + cap) * row_bytes)
+        for i, c in enumerate(ctxs):
+            base = gathered + i * (1 + cap) * row_bytes
+            c.collect_device(base + row_bytes, cap)
+            hdr["count"] = n_rows[i]
+            c._chk(c.lib.trew_hip_memcpy_h2d(c.ctx, base, hdr.ctypes.data, row_bytes), "h2d")
+        bad = np.zeros(1, dtype=capi.ROW_DTYPE)
+        bad["k"], bad["table"], bad["count"] = 5, 7, 1
+        ctxs[0]._chk(ctxs[0].lib.trew_hip_memcpy_h2d(ctxs[0].ctx, gathered + (2 * (1 + cap) + 3) * row_bytes, bad.ctypes.data, row_bytes), "h2d")
+        with pytest.raises(T.TrewHipError, match="nothing was added"):
+            ctxs[0].add_gathered_device(gathered, 3, 0, cap)
+        assert ctxs[0].collect() == parts[0]
+        assert ctxs[2].add_gathered_device(gathered, 3, 2, cap) == max(n_rows)  # rank 2 skips its own (damaged) slice by index
+        assert ctxs[2].collect() == want
+        ctxs[0].free(gathered)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_fallback_paths_are_live_and_exact():
+    """The kernels' rare fall-back paths, each forced by a crafted input, counted (trew_hip_debug_counters) and checked
+    against the oracle:
+      * decide()'s speculative skip refused -> the segment is decided again with every k counted.  (AC)n: k = 5 has one run
+        per window (bases i and i+5 always differ) and a 51 % class, it is passed over; k = 6 and 8 are accepted at 1.0,
+        k = 10 is accepted too -- a multiple of the skipped 5, which the reference closed when it accepted k = 5
+        (kmer.cpp:2225-2236): the check fails and the strict pass must give the reference's answer;
+      * eval_runs() with more than 64 runs -> classes counted window by window (that same k = 5: 71 runs in a 75-bp half);
+      * the wide table's wait for a slot's ready bit given up (TREW_FLAG_DEBUG_WIDE_NO_WAIT makes every wait time out at
+        once): lanes that lose a claim race go on probing and leave duplicate slots, which collect merges."""
+    from helpers import periodic
+
+    reads = [periodic("AC", 150, i & 1).encode() for i in range(64)] + [periodic("AG", 121, 0).encode()] * 8
+    want = O.run_short(O.OracleParams(), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 20) as t:
+        t.submit_reads(reads)
+        t.wait()
+        got = t.collect()
+        c = t.debug_counters()
+        assert got == want
+        assert c["strict_rerun"] >= 64 and c["windows_fallback"] >= 64 and c["wide_spin_timeout"] == 0, c
+        assert c["inserted"] == sum(len(v) for v in got.values()) and c["inserted_wide"] == 0
+        t.reset_tables()
+        assert all(v == 0 for v in t.debug_counters().values())
+    # ordinary reads take none of these paths often: the counters are not a hot path
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 20000, 150)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=20008, max_batch_words=1 << 22) as t:
+        t.submit_reads([buf[s:e + 1] for s, e in zip(st, nd)])
+        t.wait()
+        c = t.debug_counters()
+        assert c["windows_fallback"] < 2000 and c["strict_rerun"] < 2000, c  # 20 000 reads, 450 of them repeats
+    # wide keys, many waves inserting the same new keys at once
+    import random
+    rnd = random.Random(77)
+    units = ["".join(rnd.choice("ACGT") for _ in range(k)) for k in (33, 40, 47, 52, 64)]
+    wide = [periodic(units[i % 5], 600, (i * 7) % 33).encode() for i in range(3000)]
+    want = O.run_short(O.OracleParams(max_mer=64), wide)
+    assert any(k > 32 for tb in want.values() for (k, _) in tb)
+    with T.TrewHip(mode=T.MODE_SHORT, max_mer=64, max_batch_reads=len(wide) + 8, max_batch_words=1 << 22, flags=T.FLAG_DEBUG_WIDE_NO_WAIT) as t:
+        t.submit_reads(wide)
+        t.wait()
+        assert t.collect() == want
+        c = t.debug_counters()
+        assert c["wide_spin_timeout"] > 0 and c["inserted_wide"] >= sum(1 for tb in want.values() for (k, _) in tb if k > 32), c
 
 
 def test_wide_keys_shared_by_a_class_and_its_reverse_complement():

@@ -91,3 +91,17 @@ def test_two_ranks_device_tensor_exchange_against_the_oracle():
            "--master-port", str(port), os.path.join(ROOT, "tests", "harness", "two_rank_exchange.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0 and "TWO_RANK_EXCHANGE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_two_ranks_at_config5_offsets():
+    """The same two-rank device exchange with the ranks standing in for ranks 6 and 7 of config 5 (1 B reads over 8 GPUs:
+    read ranges starting at 750 000 000 and 875 000 000), 40 000 reads each; merged tables = oracle on both ranges."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.update(TREW_TEST_TOTAL="1000000000", TREW_TEST_WORLD="8", TREW_TEST_RANKS="6,7", TREW_TEST_TAKE="40000")
+    port = 29860 + os.getpid() % 40
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "harness", "two_rank_exchange.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "TWO_RANK_EXCHANGE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "(750000000, 750040000), (875000000, 875040000)" in r.stdout

@@ -1,41 +1,184 @@
-// Micro-benchmark: issue rate of the integer VALU ops the TREW kernels are made of (gfx950).
-// build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate ; run on the GPU box.
-// Every op is emitted through inline asm so that the compiler cannot fold the chains (an earlier
-// version of this tool let LLVM simplify the xor chain and reported an impossible 1.5 cycles).
+// Micro-benchmark: issue rate of the integer VALU ops the TREW kernels are made of (gfx950), and the clock the chip holds
+// while running them.
+// build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o tools/valu_rate ; run on the GPU box:
+//   tools/valu_rate [waves_per_simd = 8] [json]
+// Every op is emitted through inline asm so that the compiler cannot fold the chains (an earlier version of this tool let
+// LLVM simplify the xor chain and reported an impossible 1.5 cycles).  Eight independent chains per wave, `waves_per_simd`
+// waves on every SIMD.  Cycles are SHADER cycles measured in the kernel (s_memtime around the loop, median over waves), so
+// the figures do not depend on the clock the chip happens to hold; the clock itself is reported as
+// delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
 #define REP8(X) X X X X X X X X
+// one "round" = 8 instructions, one per chain; OPS2(a, b) is the text of `a = op(a, b)`
+#define CHAIN8(OPS2)                                                                                                                   \
+    asm volatile(OPS2("%0", "%1") OPS2("%1", "%2") OPS2("%2", "%3") OPS2("%3", "%4") OPS2("%4", "%5") OPS2("%5", "%6") OPS2("%6", "%7") \
+                     OPS2("%7", "%0")                                                                                                  \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)                                      \
+                 : "s"(s))
+#define CHAIN8_64(OPS2)                                                                                                                \
+    asm volatile(OPS2("%0", "%1") OPS2("%1", "%2") OPS2("%2", "%3") OPS2("%3", "%4") OPS2("%4", "%5") OPS2("%5", "%6") OPS2("%6", "%7") \
+                     OPS2("%7", "%0")                                                                                                  \
+                 : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)                                      \
+                 : "s"(s))
+
+#define OP_XOR(a, b) "v_xor_b32 " a ", " b ", " a "\n"
+#define OP_ALIGNBIT(a, b) "v_alignbit_b32 " a ", " b ", " a ", %8\n"
+#define OP_BCNT(a, b) "v_bcnt_u32_b32 " a ", " b ", " a "\n"
+#define OP_BITOP3(a, b) "v_bitop3_b32 " a ", " a ", " b ", " b " bitop3:0x48\n"
+#define OP_ADD(a, b) "v_add_u32 " a ", " b ", " a "\n"
+#define OP_LSHR32(a, b) "v_lshrrev_b32 " a ", %8, " a "\n"
+#define OP_LSHLOR(a, b) "v_lshl_or_b32 " a ", " b ", %8, " a "\n"
+#define OP_MAX3(a, b) "v_max3_u32 " a ", " a ", " b ", " b "\n"
+#define OP_SUB(a, b) "v_sub_u32 " a ", " b ", " a "\n"
+#define OP_AND(a, b) "v_and_b32 " a ", " b ", " a "\n"
+#define OP_BFE(a, b) "v_bfe_u32 " a ", " b ", %8, 5\n"
+#define OP_PERM(a, b) "v_perm_b32 " a ", " a ", " b ", " b "\n"
+#define OP_CMP(a, b) "v_cmp_le_u32 vcc, " a ", " b "\n"
+#define OP_MOV(a, b) "v_mov_b32 " a ", " b "\n"
+#define OP_LSHR64(a, b) "v_lshrrev_b64 " a ", %8, " b "\n"
+#define OP_LSHL64(a, b) "v_lshlrev_b64 " a ", %8, " b "\n"
+#define OP_MADU64(a, b) "v_mad_u64_u32 " a ", vcc, " b ", " b ", " a "\n"
+#define OP_ADDC(a, b) "v_add_co_u32 " a ", vcc, " b ", " a "\n"
+#define OP_CNDMASK(a, b) "v_cndmask_b32 " a ", " a ", " b ", vcc\n"
+#define OP_MBCNT(a, b) "v_mbcnt_lo_u32_b32 " a ", " b ", " a "\n"
+#define OP_FFBL(a, b) "v_ffbl_b32 " a ", " b "\n"
+#define OP_BFREV(a, b) "v_bfrev_b32 " a ", " b "\n"
+#define OP_MULLO(a, b) "v_mul_lo_u32 " a ", " b ", " a "\n"
+#define OP_SAD(a, b) "v_sad_u8 " a ", " a ", " b ", " a "\n"
+#define OP_DOT4(a, b) "v_dot4_u32_u8 " a ", " a ", " b ", " a "\n"
+
+enum { N_OPS = 26 };
+static const char *kNames[N_OPS] = {"v_xor_b32",     "v_alignbit_b32", "v_bcnt_u32_b32", "v_bitop3_b32",  "v_add_u32",      "v_lshrrev_b32", "v_lshl_or_b32",
+                                    "v_max3_u32",    "v_sub_u32",      "v_and_b32",      "v_bfe_u32",     "v_perm_b32",     "v_cmp_le_u32",  "v_mov_b32",
+                                    "v_lshrrev_b64", "v_lshlrev_b64",  "v_mad_u64_u32",  "v_add_co_u32",  "v_cndmask_b32",  "v_mbcnt_lo",    "v_ffbl_b32",
+                                    "v_bfrev_b32",   "v_mul_lo_u32",   "v_sad_u8",       "v_dot4_u32_u8", "xor+alignbit+bcnt mix (the prefilter's k loop)"};
+
 template <int OP>
-__global__ __launch_bounds__(256) void k(unsigned *out, int iters, unsigned s) {
+__global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stamps, int iters, unsigned s) {
     unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 ^ 0x55, a5 = a0 + 9, a6 = a0 * 11, a7 = ~a0;
+    unsigned long long b0 = a0 * 0x9E3779B97F4A7C15ull, b1 = b0 * 3, b2 = b0 * 5, b3 = b0 * 7, b4 = ~b0, b5 = b0 + 9, b6 = b0 * 11, b7 = b0 ^ 0x5555;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
-        if (OP == 0) { REP8(asm volatile("v_xor_b32 %0, %1, %0\n v_xor_b32 %1, %2, %1\n v_xor_b32 %2, %3, %2\n v_xor_b32 %3, %4, %3\n v_xor_b32 %4, %5, %4\n v_xor_b32 %5, %6, %5\n v_xor_b32 %6, %7, %6\n v_xor_b32 %7, %0, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
-        if (OP == 1) { REP8(asm volatile("v_alignbit_b32 %0, %1, %0, %8\n v_alignbit_b32 %1, %2, %1, %8\n v_alignbit_b32 %2, %3, %2, %8\n v_alignbit_b32 %3, %4, %3, %8\n v_alignbit_b32 %4, %5, %4, %8\n v_alignbit_b32 %5, %6, %5, %8\n v_alignbit_b32 %6, %7, %6, %8\n v_alignbit_b32 %7, %0, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(s));) }
-        if (OP == 2) { REP8(asm volatile("v_bcnt_u32_b32 %0, %1, %0\n v_bcnt_u32_b32 %1, %2, %1\n v_bcnt_u32_b32 %2, %3, %2\n v_bcnt_u32_b32 %3, %4, %3\n v_bcnt_u32_b32 %4, %5, %4\n v_bcnt_u32_b32 %5, %6, %5\n v_bcnt_u32_b32 %6, %7, %6\n v_bcnt_u32_b32 %7, %0, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
-        if (OP == 3) { REP8(asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x48\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x48\n v_bitop3_b32 %2, %2, %3, %4 bitop3:0x48\n v_bitop3_b32 %3, %3, %4, %5 bitop3:0x48\n v_bitop3_b32 %4, %4, %5, %6 bitop3:0x48\n v_bitop3_b32 %5, %5, %6, %7 bitop3:0x48\n v_bitop3_b32 %6, %6, %7, %0 bitop3:0x48\n v_bitop3_b32 %7, %7, %0, %1 bitop3:0x48" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
-        if (OP == 4) { REP8(asm volatile("v_add_u32 %0, %1, %0\n v_add_u32 %1, %2, %1\n v_add_u32 %2, %3, %2\n v_add_u32 %3, %4, %3\n v_add_u32 %4, %5, %4\n v_add_u32 %5, %6, %5\n v_add_u32 %6, %7, %6\n v_add_u32 %7, %0, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
-    }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-}
-int main() {
-    unsigned *d; hipMalloc(&d, 256 * 8192 * 4);
-    const char *names[5] = {"v_xor_b32 (VOP2)", "v_alignbit_b32 (VOP3)", "v_bcnt_u32_b32 (VOP3)", "v_bitop3_b32 (VOP3)", "v_add_u32 (VOP2)"};
-    for (int op = 0; op < 5; op++) {
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        const int iters = 4000, blocks = 256 * 8;  // 8 blocks of 256 per CU = 8 waves/SIMD
-        for (int rep = 0; rep < 2; rep++) {
-            hipEventRecord(e0);
-            if (op == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d, iters, 7u);
-            if (op == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, iters, 7u);
-            if (op == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d, iters, 7u);
-            if (op == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d, iters, 7u);
-            if (op == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d, iters, 7u);
-            hipEventRecord(e1); hipEventSynchronize(e1);
+        if (OP == 0) { REP8(CHAIN8(OP_XOR);) }
+        if (OP == 1) { REP8(CHAIN8(OP_ALIGNBIT);) }
+        if (OP == 2) { REP8(CHAIN8(OP_BCNT);) }
+        if (OP == 3) { REP8(CHAIN8(OP_BITOP3);) }
+        if (OP == 4) { REP8(CHAIN8(OP_ADD);) }
+        if (OP == 5) { REP8(CHAIN8(OP_LSHR32);) }
+        if (OP == 6) { REP8(CHAIN8(OP_LSHLOR);) }
+        if (OP == 7) { REP8(CHAIN8(OP_MAX3);) }
+        if (OP == 8) { REP8(CHAIN8(OP_SUB);) }
+        if (OP == 9) { REP8(CHAIN8(OP_AND);) }
+        if (OP == 10) { REP8(CHAIN8(OP_BFE);) }
+        if (OP == 11) { REP8(CHAIN8(OP_PERM);) }
+        if (OP == 12) { REP8(CHAIN8(OP_CMP);) }
+        if (OP == 13) { REP8(CHAIN8(OP_MOV);) }
+        if (OP == 14) { REP8(CHAIN8_64(OP_LSHR64);) }
+        if (OP == 15) { REP8(CHAIN8_64(OP_LSHL64);) }
+        if (OP == 16) { REP8(asm volatile(OP_MADU64("%0", "%1") OP_MADU64("%0", "%2") OP_MADU64("%0", "%1") OP_MADU64("%0", "%2") OP_MADU64("%3", "%1") OP_MADU64("%3", "%2") OP_MADU64("%3", "%1") OP_MADU64("%3", "%2") : "+v"(b0), "+v"(a1), "+v"(a2), "+v"(b3) : : "vcc");) }
+        if (OP == 17) { REP8(CHAIN8(OP_ADDC);) }
+        if (OP == 18) { REP8(CHAIN8(OP_CNDMASK);) }
+        if (OP == 19) { REP8(CHAIN8(OP_MBCNT);) }
+        if (OP == 20) { REP8(CHAIN8(OP_FFBL);) }
+        if (OP == 21) { REP8(CHAIN8(OP_BFREV);) }
+        if (OP == 22) { REP8(CHAIN8(OP_MULLO);) }
+        if (OP == 23) { REP8(CHAIN8(OP_SAD);) }
+        if (OP == 24) { REP8(CHAIN8(OP_DOT4);) }
+        if (OP == 25) {
+            // the instruction mix of one (k, word) of the prefilter's fast path: 2 alignbit, 2 xor, 1 and, 3 bcnt
+            REP8(asm volatile("v_alignbit_b32 %4, %1, %0, %8\n v_alignbit_b32 %5, %3, %2, %8\n v_xor_b32 %4, %4, %0\n v_xor_b32 %5, %5, %2\n"
+                              "v_bcnt_u32_b32 %6, %4, %6\n v_bcnt_u32_b32 %7, %5, %7\n v_and_b32 %4, %4, %5\n v_bcnt_u32_b32 %6, %4, %6\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                              : "s"(s));)
         }
-        float ms; hipEventElapsedTime(&ms, e0, e1);
-        double winstr = (double) blocks * 4 * iters * 64;  // wave-instructions: 4 waves/block x 64 ops per iteration
-        double per_simd_cycle = winstr / (ms * 1e-3 * 2.4e9 * 1024);
-        printf("%-24s %.3f ms  %.3f wave-instr/cycle/SIMD (at 2.4 GHz)  => %.2f cycles per wave-instr\n", names[op], ms, per_simd_cycle, 1.0 / per_simd_cycle);
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (unsigned) (b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        stamps[4 * w] = t1 - t0;
+        stamps[4 * w + 1] = r1 - r0;
+        stamps[4 * w + 2] = r0;
+        stamps[4 * w + 3] = r1;
+    }
+}
+
+typedef void (*kern_t)(unsigned *, unsigned long long *, int, unsigned);
+template <int OP>
+struct Table {
+    static void fill(kern_t *t) {
+        t[OP] = k<OP>;
+        Table<OP - 1>::fill(t);
+    }
+};
+template <>
+struct Table<-1> {
+    static void fill(kern_t *) {}
+};
+
+int main(int argc, char **argv) {
+    const int wps = argc > 1 ? atoi(argv[1]) : 8;  // waves per SIMD = 256-thread blocks per CU
+    const bool json = argc > 2 && !strcmp(argv[2], "json");
+    hipDeviceProp_t prop;
+    (void) hipGetDeviceProperties(&prop, 0);
+    const int n_cu = prop.multiProcessorCount;
+    const int blocks = n_cu * wps, waves = blocks * 4;
+    unsigned *d;
+    unsigned long long *d_st;
+    (void) hipMalloc(&d, (size_t) blocks * 256 * 4);
+    (void) hipMalloc(&d_st, (size_t) waves * 32);
+    kern_t tab[N_OPS];
+    Table<N_OPS - 1>::fill(tab);
+    std::vector<unsigned long long> st(4 * (size_t) waves);
+    if (json) printf("{\"waves_per_simd\": %d, \"cycles_per_wave_inst\": {", wps);
+    double clock_sum = 0;
+    for (int op = 0; op < N_OPS; op++) {
+        hipEvent_t e0, e1;
+        (void) hipEventCreate(&e0);
+        (void) hipEventCreate(&e1);
+        const int iters = 3000;
+        for (int rep = 0; rep < 2; rep++) {
+            (void) hipEventRecord(e0);
+            hipLaunchKernelGGL(tab[op], dim3(blocks), dim3(256), 0, 0, d, d_st, iters, 7u);
+            (void) hipEventRecord(e1);
+            (void) hipEventSynchronize(e1);
+        }
+        float ms;
+        (void) hipEventElapsedTime(&ms, e0, e1);
+        (void) hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> cyc(waves), clk(waves);
+        for (int w = 0; w < waves; w++) {
+            cyc[w] = (double) st[4 * w];
+            clk[w] = (double) st[4 * w] / (double) st[4 * w + 1] * 100e6;
+        }
+        // when did the waves start and end (s_memrealtime, 100 MHz)?  All resident at once <=> every wave starts within a few
+        // microseconds of the first one and the kernel lasts as long as one wave.
+        unsigned long long r_first = ~0ull, r_last_start = 0, r_end = 0;
+        for (int w = 0; w < waves; w++) {
+            r_first = std::min(r_first, st[4 * w + 2]);
+            r_last_start = std::max(r_last_start, st[4 * w + 2]);
+            r_end = std::max(r_end, st[4 * w + 3]);
+        }
+        const double span_ms = (double) (r_end - r_first) / 100e3, start_spread_ms = (double) (r_last_start - r_first) / 100e3;
+        std::nth_element(cyc.begin(), cyc.begin() + waves / 2, cyc.end());
+        std::nth_element(clk.begin(), clk.begin() + waves / 2, clk.end());
+        const double winstr_per_wave = (double) iters * 64;  // 8 rounds of 8 instructions per iteration
+        // wps waves share one SIMD: SIMD cycles per wave-instruction = wave cycles / (instructions x waves on the SIMD)
+        const double per_inst = cyc[waves / 2] / (winstr_per_wave * wps);
+        clock_sum += clk[waves / 2];
+        if (json)
+            printf("%s\"%s\": %.2f", op ? ", " : "", kNames[op], per_inst);
+        else
+            printf("%-48s %.3f ms  %.2f SIMD cycles per wave-instruction  (in-kernel clock %.2f GHz; first wave start to last wave end %.3f ms, wave starts spread over %.3f ms, median wave %.3f ms)\n",
+                   kNames[op], ms, per_inst, clk[waves / 2] * 1e-9, span_ms, start_spread_ms, cyc[waves / 2] / clk[waves / 2] * 1e3);
+    }
+    if (json) printf("}, \"clock_ghz\": %.3f, \"source\": \"tools/valu_rate.hip: s_memtime around 192 000 instructions per wave, %d waves per SIMD, median over waves\"}\n", clock_sum / N_OPS * 1e-9, wps);
     return 0;
 }

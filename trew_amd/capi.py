@@ -18,6 +18,7 @@ MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
 FLAG_NO_FILTER = 1
 FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (tests)
 FLAG_NO_TIMING = 64  # no HIP events per submit (last_timing unavailable)
+FLAG_DEBUG_WIDE_NO_WAIT = 128  # tests: the wide table never waits for a slot's ready bit (forces its time-out path)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
 
 # every symbol include/trew_hip.h declares
@@ -30,7 +31,9 @@ EXPORTED_SYMBOLS = (
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
     "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
     "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
+    "trew_hip_add_gathered_device", "trew_hip_debug_counters",
 )
+DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide")
 
 
 class Params(C.Structure):
@@ -103,6 +106,8 @@ def load():
     lib.trew_hip_collect_device.argtypes = [vp, vp, u64, C.POINTER(u64)]
     lib.trew_hip_add_rows_device.argtypes = [vp, vp, u64]
     lib.trew_hip_merge.argtypes = [vp, vp]
+    lib.trew_hip_add_gathered_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(u64)]
+    lib.trew_hip_debug_counters.argtypes = [vp, C.POINTER(u64), i32]
     lib.trew_hip_table_pressure.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64]
     lib.trew_hip_filter_masks.argtypes = [vp, C.POINTER(Batch), vp, i32]
@@ -292,6 +297,20 @@ class TrewHip:
 
     def add_rows_device(self, d_rows, n_rows):
         self._chk(self.lib.trew_hip_add_rows_device(self.ctx, d_rows, n_rows), "trew_hip_add_rows_device")
+
+    def add_gathered_device(self, d_buf, n_slices, own_slice, slice_rows, producer_stream=None):
+        """One kernel over the gather buffer of the table exchange (n_slices x (1 + slice_rows) rows, headers in row 0 of each
+        slice): adds every slice but own_slice.  Returns the largest header count; if it exceeds slice_rows nothing was added."""
+        mx = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_add_gathered_device(self.ctx, d_buf, n_slices, own_slice, slice_rows, producer_stream, C.byref(mx)),
+                  "trew_hip_add_gathered_device")
+        return int(mx.value)
+
+    def debug_counters(self):
+        """{name: count} of the kernels' rare fall-back paths since the last reset_tables (DEBUG_COUNTERS)."""
+        out = (C.c_uint64 * len(DEBUG_COUNTERS))()
+        self._chk(self.lib.trew_hip_debug_counters(self.ctx, out, len(DEBUG_COUNTERS)), "trew_hip_debug_counters")
+        return dict(zip(DEBUG_COUNTERS, (int(x) for x in out)))
 
     def merge_from(self, other):
         """Add every row of `other`'s tables (another context, same or another GPU) into this context's tables."""

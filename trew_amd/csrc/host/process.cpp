@@ -573,6 +573,7 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
         w->t_scan += secs(t0, t1);
         // a block holds at most reads_cap sequence lines and words_cap/2 words: it always fits an empty batch
         if (acc_reads + keep > w->reads_cap || acc_words + need_words > w->words_cap) close_batch();
+        if (keep > w->reads_cap || need_words > w->words_cap) die("internal error: one block's reads do not fit the slot buffer");
         if (!buffers_free) {
             const clk::time_point tw = clk::now();
             if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
@@ -656,6 +657,7 @@ static void pair_worker_loop(Scanner *s, Worker *w, PairJob *job) {
                 words += need;
                 n++;
             }
+            if (n == 0) die("internal error: a pair does not fit the slot buffer");  // MAX_SEQ bounds a pair far below words_cap; never spin
             const clk::time_point tw = clk::now();
             if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
             const clk::time_point t2 = clk::now();
@@ -746,6 +748,13 @@ static bool run_blocks(Scanner *s, const char *name, bool long_mode, int slice_l
 // per device) and only the merged rows cross PCIe.
 static ResultMapData collect_tables(Scanner *s) {
     for (size_t d = 1; d < s->dev.size(); d++) {
+        // Mid-file drains only keep EACH device at or below half full; the union of several devices' keys can exceed
+        // device 0's partitions plus its spill log.  So device 0 is emptied into host memory whenever it is under
+        // pressure before it takes another device's rows (no worker is running any more: no lock needed).
+        if (under_pressure(s->dev[0]->ctx)) {
+            drain_device(s, s->dev[0].get());
+            s->drains++;
+        }
         if (trew_hip_merge(s->dev[0]->ctx, s->dev[d]->ctx)) hip_die(s->dev[0]->ctx, "trew_hip_merge");
         if (trew_hip_reset_tables(s->dev[d]->ctx)) hip_die(s->dev[d]->ctx, "trew_hip_reset_tables");
     }

@@ -71,6 +71,8 @@ struct trew_hip_ctx {
     // persistent scratch of trew_hip_add_rows / trew_hip_merge (grow-only)
     trew_hip_row *d_add_rows = nullptr;
     u64 add_cap = 0;
+    u32 *d_row_flags = nullptr;  // kRowFlagWords words: verdict of the validation pass of the row-adding entry points
+    hipEvent_t ev_producer = nullptr;  // orders slot 0's stream behind a caller's stream (trew_hip_add_gathered_device)
     std::mutex table_mu;  // collect / reset / add_rows / merge are whole-table operations: one at a time
 };
 
@@ -198,6 +200,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         }
         // spill log: 1/16 of the table's slots, at least 64 k rows
         ctx->wide.spill_cap = (u32) std::max<u64>(1ull << 16, ctx->table_slots >> 4);
+        ctx->wide.spin_limit = (p.flags & TREW_FLAG_DEBUG_WIDE_NO_WAIT) ? 0u : (1u << 20);
         if ((e = hipMalloc((void **) &ctx->wide.spill_rows, (size_t) ctx->wide.spill_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(spill log)", e);
         if ((e = hipMalloc((void **) &ctx->wide.spill_n, 4)) != hipSuccess) return bail("hipMalloc(spill counter)", e);
         if ((e = hipMemset(ctx->wide.spill_n, 0, 4)) != hipSuccess) return bail("hipMemset", e);
@@ -207,6 +210,8 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         ctx->table.wide = dw;
     }
 
+    if ((e = hipMalloc((void **) &ctx->d_row_flags, kRowFlagWords * 4)) != hipSuccess) return bail("hipMalloc(row flags)", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_producer, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     ctx->slots.resize((size_t) p.n_slots);
     for (auto &s : ctx->slots) {
         if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -274,6 +279,8 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
     if (ctx->d_add_rows) (void) hipFree(ctx->d_add_rows);
+    if (ctx->d_row_flags) (void) hipFree(ctx->d_row_flags);
+    if (ctx->ev_producer) (void) hipEventDestroy(ctx->ev_producer);
     delete ctx;
 }
 
@@ -356,6 +363,13 @@ static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevB
     if (!b->offsets && !b->lengths && b->uniform_stride < 3 * ((b->uniform_length + 31) / 32))
         return fail(ctx, "uniform_stride smaller than the packed read");
     if ((b->offsets == nullptr) != (b->lengths == nullptr)) return fail(ctx, "offsets and lengths must both be given or both be NULL");
+    // Index widths of the kernels: worklist entries are u32 unit indices, a read starts at a u32 word offset with explicit
+    // offsets and at unit * stride (64-bit arithmetic, get_read) without.  max_batch_reads <= 0xfffffff0 bounds the first for
+    // every batch; a uniform batch (device-resident ones included, where no n_words check applies) must also keep the
+    // word index of its last read inside what one allocation can hold.
+    if (b->n_reads > 0xfffffff0ull) return fail(ctx, "batch has more reads than the kernels' 32-bit unit index holds");
+    if (!b->offsets && b->n_reads && (b->n_reads - 1) > (0xffffffffffffffffull / 4ull - 4096ull) / std::max<u64>(1, b->uniform_stride))
+        return fail(ctx, "uniform batch: n_reads * uniform_stride overflows the 64-bit word index");
     db->uniform_length = b->uniform_length;
     db->uniform_stride = b->uniform_stride;
     db->n_reads = b->n_reads;
@@ -439,16 +453,33 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
         HIPCHK(ctx, hipMemsetAsync(s.res.seq_low_hi, 0, db.n_reads * 8, s.stream));
     }
     const u32 wl_cap = (u32) ctx->p.max_batch_reads;
-    u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;        // clean: cleared by the previous launch
+    // Counter block of this launch: clean because the exact kernel of the previous successful launch cleared it (or init did).
+    // n_launches only advances once BOTH kernels are queued: if anything below fails, the block may hold a half-built worklist
+    // and no exact kernel will clear the other one, so the failing path wipes both before returning (submit_failed).
+    u32 *const wl_count = s.d_wl_count + (s.n_launches & 1) * kWlCountWords;
     u32 *const wl_count_next = s.d_wl_count + ((s.n_launches + 1) & 1) * kWlCountWords;  // this launch clears it
-    s.n_launches++;
+    auto submit_failed = [&](int rc) {
+        const std::string keep = g_thread_error;  // the clean-up must not replace the text of the failure
+        (void) hipMemsetAsync(s.d_wl_count, 0, 2 * kWlCountBytes, s.stream);
+        (void) hipStreamSynchronize(s.stream);
+        g_thread_error = keep;
+        return rc;
+    };
+#define SUBMIT_CHK(expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            g_thread_error = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return submit_failed((int) e_);                                                    \
+        }                                                                                      \
+    } while (0)
     const int2 *d_thr = nullptr;
-    if (int rc = stage_thresholds(ctx, s, db, &d_thr)) return rc;
+    if (int rc = stage_thresholds(ctx, s, db, &d_thr)) return submit_failed(rc);
     const bool timed = !(ctx->p.flags & TREW_FLAG_NO_TIMING);
     hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
-    if (timed) HIPCHK(ctx, hipEventRecord(ev[0], s.stream));
-    HIPCHK(ctx, launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, wl_cap, nullptr, 0, ctx->table.overflow, d_thr));
-    if (timed) HIPCHK(ctx, hipEventRecord(ev[1], s.stream));
+    if (timed) SUBMIT_CHK(hipEventRecord(ev[0], s.stream));
+    SUBMIT_CHK(launch_filter(s.stream, (u32) ctx->n_cu, max_seg, ctx->dp, db, s.d_wl, wl_count, wl_cap, nullptr, 0, ctx->table.overflow, d_thr));
+    if (timed) SUBMIT_CHK(hipEventRecord(ev[1], s.stream));
     // LDS working set of the exact kernel: the longest segment it may stage (the whole
     // read for k_mer_target / the whole-read check; a slice pair in long mode)
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
@@ -456,8 +487,10 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
     const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
     DevTable tbl = ctx->table;
     if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
-    HIPCHK(ctx, launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
-    if (timed) HIPCHK(ctx, hipEventRecord(ev[2], s.stream));
+    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
+    if (timed) SUBMIT_CHK(hipEventRecord(ev[2], s.stream));
+#undef SUBMIT_CHK
+    s.n_launches++;
     s.n_submits++;
     return 0;
 }
@@ -482,7 +515,6 @@ static int check_diag(trew_hip_ctx *ctx, u32 (&diag)[kDiagWords]) {
     if (diag[kDiagOverflow]) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
     if (diag[kDiagWorklistDrop]) return fail(ctx, "internal error: the prefilter worklist overflowed (survivors were dropped)");
     if (diag[kDiagIntentDrop]) return fail(ctx, "internal error: a pair logged more than 32 deferred emissions (some were dropped)");
-    if (diag[kDiagBadRow]) return fail(ctx, "trew_hip_add_rows_device: row out of range");
     return 0;
 }
 
@@ -516,7 +548,10 @@ static int compact_to(trew_hip_ctx *ctx, int table, trew_hip_row *d_rows, u64 ca
     if (n_spill) {
         if (table < 0) {  // the log is device-resident: append it as it is
             if (d_rows && n + n_spill <= cap)
-                HIPCHK(ctx, hipMemcpy(d_rows + n, ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToDevice));
+                {  // on the stream the compaction ran on, and complete before anyone reads d_rows (callers use other streams)
+                    HIPCHK(ctx, hipMemcpyAsync(d_rows + n, ctx->wide.spill_rows, (size_t) n_spill * sizeof(trew_hip_row), hipMemcpyDeviceToDevice, st));
+                    HIPCHK(ctx, hipStreamSynchronize(st));
+                }
             n += n_spill;
         } else {  // one table only: select on the host (rare path)
             std::vector<trew_hip_row> sp(n_spill);
@@ -590,6 +625,7 @@ static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.spill_n, 0, 4));
+    HIPCHK(ctx, fallback_counters_clear());
     return 0;
 }
 
@@ -619,9 +655,16 @@ extern "C" int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, 
     return 0;
 }
 
-static int add_device_rows_locked(trew_hip_ctx *ctx, const trew_hip_row *d_rows, u64 n_rows) {
-    HIPCHK(ctx, launch_add_rows(ctx->slots[0].stream, ctx->table, d_rows, n_rows));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->slots[0].stream));
+// Adds n_rows device-resident rows on slot 0's stream.  validate: run the device-side check first (rows of unknown origin);
+// the add is all or nothing -- with a bad row nothing is added and the call fails, the context stays usable.
+static int add_device_rows_locked(trew_hip_ctx *ctx, const trew_hip_row *d_rows, u64 n_rows, bool validate) {
+    hipStream_t st = ctx->slots[0].stream;
+    if (validate) HIPCHK(ctx, hipMemsetAsync(ctx->d_row_flags, 0, kRowFlagWords * 4, st));
+    HIPCHK(ctx, launch_add_rows(st, ctx->table, d_rows, n_rows, validate ? ctx->d_row_flags : nullptr));
+    u32 flags[kRowFlagWords] = {0, 0, 0, 0};
+    if (validate) HIPCHK(ctx, hipMemcpyAsync(flags, ctx->d_row_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (flags[kRowFlagBad]) return fail(ctx, "trew_hip_add_rows_device: row out of range (nothing was added)");
     u32 diag[kDiagWords];
     return check_diag(ctx, diag);
 }
@@ -636,7 +679,7 @@ extern "C" int trew_hip_add_rows(trew_hip_ctx *ctx, const trew_hip_row *rows, ui
     if (int rc = sync_all(ctx)) return rc;
     if (int rc = ensure_rows(ctx, &ctx->d_add_rows, &ctx->add_cap, n_rows)) return rc;  // persistent scratch: no malloc/free per call
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_add_rows, rows, n_rows * sizeof(trew_hip_row), hipMemcpyHostToDevice, ctx->slots[0].stream));
-    return add_device_rows_locked(ctx, ctx->d_add_rows, n_rows);
+    return add_device_rows_locked(ctx, ctx->d_add_rows, n_rows, false);  // validated above, on the host
 }
 
 extern "C" int trew_hip_add_rows_device(trew_hip_ctx *ctx, const trew_hip_row *d_rows, uint64_t n_rows) {
@@ -646,7 +689,43 @@ extern "C" int trew_hip_add_rows_device(trew_hip_ctx *ctx, const trew_hip_row *d
     std::lock_guard<std::mutex> lk(ctx->table_mu);
     if (int rc = sync_all(ctx)) return rc;
     HIPCHK(ctx, hipDeviceSynchronize());  // the rows may have been produced on a stream of the caller's (an RCCL all_gather)
-    return add_device_rows_locked(ctx, d_rows, n_rows);
+    return add_device_rows_locked(ctx, d_rows, n_rows, true);
+}
+
+extern "C" int trew_hip_add_gathered_device(trew_hip_ctx *ctx, const trew_hip_row *d_buf, uint32_t n_slices, uint32_t own_slice,
+                                            uint64_t slice_rows, void *producer_stream, uint64_t *max_rows) {
+    if (!ctx) return -1;
+    if (!d_buf || n_slices == 0 || own_slice >= n_slices) return fail(ctx, "trew_hip_add_gathered_device: bad arguments");
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    hipStream_t st = ctx->slots[0].stream;
+    if (producer_stream) {  // device-side ordering behind the collective: no host synchronisation between the two
+        HIPCHK(ctx, hipEventRecord(ctx->ev_producer, (hipStream_t) producer_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_producer, 0));
+    } else {
+        HIPCHK(ctx, hipDeviceSynchronize());
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_row_flags, 0, kRowFlagWords * 4, st));
+    HIPCHK(ctx, launch_add_gathered(st, ctx->table, d_buf, n_slices, own_slice, slice_rows, ctx->d_row_flags));
+    u32 flags[kRowFlagWords] = {0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(flags, ctx->d_row_flags, sizeof(flags), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (max_rows) *max_rows = ((u64) flags[kRowFlagMaxHi] << 32) | flags[kRowFlagMaxLo];
+    if (flags[kRowFlagBad]) return fail(ctx, "trew_hip_add_gathered_device: row out of range (nothing was added)");
+    if (flags[kRowFlagOverflow]) return 0;  // a slice holds more rows than fit: nothing was added, *max_rows says how many there are
+    u32 diag[kDiagWords];
+    return check_diag(ctx, diag);
+}
+
+extern "C" int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n) {
+    if (!ctx || !out || n < 0) return -1;
+    if (int rc = sync_all(ctx)) return rc;
+    u32 diag[kDiagWords], fb[kFallbackWords];
+    HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, fallback_counters_read(fb));
+    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide]};
+    for (int i = 0; i < n; i++) out[i] = i < TREW_DEBUG_COUNTERS ? v[i] : 0;
+    return 0;
 }
 
 extern "C" int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src) {
@@ -665,9 +744,11 @@ extern "C" int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src) {
     if (int rc = sync_all(dst)) return rc;
     if (int rc = ensure_rows(dst, &dst->d_add_rows, &dst->add_cap, n)) return rc;
     // device to device: over xGMI when the contexts sit on two GPUs, a plain copy when they share one
-    HIPCHK(dst, hipMemcpyPeer(dst->d_add_rows, dst->p.device, src->d_collect_rows, src->p.device, n * sizeof(trew_hip_row)));
+    // (queued on the stream that launches the add kernel, so the kernel is ordered behind the copy by the stream itself;
+    // src's rows are complete: compact_to synchronised its stream)
     HIPCHK(dst, hipSetDevice(dst->p.device));
-    return add_device_rows_locked(dst, dst->d_add_rows, n);
+    HIPCHK(dst, hipMemcpyPeerAsync(dst->d_add_rows, dst->p.device, src->d_collect_rows, src->p.device, n * sizeof(trew_hip_row), dst->slots[0].stream));
+    return add_device_rows_locked(dst, dst->d_add_rows, n, false);  // rows compacted from a table of this library
 }
 
 extern "C" int trew_hip_segment_results(trew_hip_ctx *ctx, int slot, int32_t *k_high, int32_t *k_low,

@@ -48,9 +48,22 @@ enum {
     kDiagIntentDrop = 2,   // the pair driver logged more than 32 deferred emissions for one pair (cannot happen: <= 20)
     kDiagInserted = 3,     // keys inserted into the narrow table (occupancy, trew_hip_table_pressure)
     kDiagInsertedWide = 4, // keys inserted into the wide table
-    kDiagBadRow = 5,       // trew_hip_add_rows_device met a row with k / table out of range
+    kDiagBadRow = 5,       // unused since ABI 3 (rows are validated in a pass of their own, see kRowFlag*)
     kDiagWords = 16
 };
+
+// How often the kernels took their rare fall-back paths (trew_hip_debug_counters).  A module-level device array rather than
+// words of DevTable::overflow: decide() and eval_runs() have no table pointer, and the exact kernels have no SGPRs to spare
+// for one -- the address of a __device__ variable is a literal.  One array per device, shared by the contexts on it.
+enum {
+    kFallbackStrictRerun = 0,   // decide(): a speculative skip failed its check and the segment was decided again, every k counted
+    kFallbackWindows = 1,       // eval_runs(): more than 64 runs, classes counted per window (eval_k_windows)
+    kFallbackWideSpin = 2,      // table_add_wide(): gave up waiting for a slot's ready bit (a duplicate slot may follow; collect merges)
+    kFallbackWords = 4
+};
+
+// device scratch of the row-adding entry points (table_check_rows_kernel & co): validation is a pass of its own, so an add is all or nothing
+enum { kRowFlagBad = 0, kRowFlagOverflow = 1, kRowFlagMaxLo = 2, kRowFlagMaxHi = 3, kRowFlagWords = 4 };
 
 struct DevTable {
     u64 *keys;    // 0 = empty
@@ -71,6 +84,7 @@ struct DevWide {
     u32 spill_cap;
     trew_hip_row *spill_rows;
     u32 *spill_n;
+    u32 spin_limit;  // polls of a claimed slot's ready bit before table_add_wide gives up on it (0 with TREW_FLAG_DEBUG_WIDE_NO_WAIT)
 };
 
 // per-read outputs of TREW_MODE_SEGMENT

@@ -117,6 +117,12 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
     return hipGetLastError();
 }
 
+hipError_t fallback_counters_read(u32 *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fallback), sizeof(u32) * kFallbackWords); }
+hipError_t fallback_counters_clear() {
+    const u32 z[kFallbackWords] = {0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fallback), z, sizeof(z));
+}
+
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_lds_bytes(cap, rawwords, wordbytes); }
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable &T,
@@ -178,9 +184,23 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     return hipGetLastError();
 }
 
-hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n) {
+// flags: device scratch (kRowFlagWords words, zeroed by the caller on the same stream) or nullptr when the rows were
+// validated on the host.  With flags the check kernel runs first and the add kernel behind it does nothing if it found a bad row.
+hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n, u32 *d_flags) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(table_add_rows_kernel, dim3((u32) ((n + 255) / 256)), dim3(256), 0, st, T, d_rows, n);
+    const dim3 grid((u32) ((n + 255) / 256));
+    if (d_flags) hipLaunchKernelGGL(table_check_rows_kernel, grid, dim3(256), 0, st, d_rows, n, d_flags);
+    hipLaunchKernelGGL(table_add_rows_kernel, grid, dim3(256), 0, st, T, d_rows, n, (const u32 *) d_flags);
+    return hipGetLastError();
+}
+
+// the gather buffer of the cross-GPU exchange: n_slices x (1 + slice_rows) rows, headers in row 0 of each slice
+hipError_t launch_add_gathered(hipStream_t st, const DevTable &T, const trew_hip_row *d_buf, u32 n_slices, u32 own, u64 slice_rows, u32 *d_flags) {
+    const u64 total = (u64) n_slices * (slice_rows + 1ull);
+    if (total == 0) return hipSuccess;
+    const dim3 grid((u32) ((total + 255) / 256));
+    hipLaunchKernelGGL(table_check_gathered_kernel, grid, dim3(256), 0, st, d_buf, n_slices, own, slice_rows, d_flags);
+    hipLaunchKernelGGL(table_add_gathered_kernel, grid, dim3(256), 0, st, T, d_buf, n_slices, own, slice_rows, (const u32 *) d_flags);
     return hipGetLastError();
 }
 

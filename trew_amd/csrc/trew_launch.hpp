@@ -15,7 +15,10 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len);
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes);
-hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n);
+hipError_t fallback_counters_read(u32 *out);  // kFallbackWords words of the current device
+hipError_t fallback_counters_clear();
+hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n, u32 *d_flags);
+hipError_t launch_add_gathered(hipStream_t st, const DevTable &T, const trew_hip_row *d_buf, u32 n_slices, u32 own, u64 slice_rows, u32 *d_flags);
 hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n);
 hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);

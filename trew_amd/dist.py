@@ -10,9 +10,10 @@ hash tables whose slot layout differs per GPU, so they are made reducible first:
   4. ONE all_reduce(sum) of that vector (RCCL over xGMI with backend "nccl";
      gloo in the CPU tests).
 
-allreduce_table_device() is what bench.py calls for N > 1: the rows are compacted on the device,
-all_gathered as device tensors (RCCL) and merged by the device count table itself (the table IS a
-sum-merge structure) -- no host round trip, no dictionary.  allreduce_rows_into_table() is the same
+allreduce_table_device() is what bench.py calls for N > 1: the rows are compacted on the device into a
+fixed-capacity slice, ONE all_gather_into_tensor (RCCL) moves the slices, and one kernel merges them
+into the device count table itself (the table IS a sum-merge structure) -- no host round trip between
+compaction and merge, no dictionary.  allreduce_rows_into_table() is the same
 exchange with host-side row arrays (gloo rehearsals and the CPU tests); allreduce_tables() /
 allreduce_rows() are the dictionary + ONE all_reduce formulation of SURVEY 8(e), kept as the
 reference the other two are tested against.
@@ -173,17 +174,26 @@ def allreduce_rows_into_table(ctx, rows, device="cpu", group=None):
 
 
 def allreduce_table_device(ctx, device, group=None, force_collectives=False, rows_on_every_rank=False):
-    """The reduction bench.py uses for N > 1 with backend "nccl" (= RCCL): nothing leaves HBM until the final rows.
+    """The reduction bench.py uses for N > 1 with backend "nccl" (= RCCL): ONE collective, nothing leaves HBM until the
+    final rows, no host round trip between the compaction and the merge.
 
-      1. trew_hip_collect_device compacts this rank's table into a device tensor (32 B per row: table, k, word, count);
-      2. all_gather of the row counts, all_gather of the (padded) row tensors -- RCCL over xGMI, KB..MB, latency-bound;
-      3. every OTHER rank's rows are added into this rank's device table (trew_hip_add_rows_device: one kernel of
-         atomic adds per peer) -- the table is the sum-merge structure, no dictionary is built anywhere;
-      4. trew_hip_collect returns the merged rows; every rank's table now holds the global sums.
+      1. trew_hip_collect_device compacts this rank's table straight into its slice of a fixed-capacity exchange buffer:
+         1 + cap rows of 32 B (table, k, word, count), row 0 = header carrying the row count;
+      2. ONE all_gather_into_tensor of the slices -- RCCL over xGMI, KB..MB, latency-bound;
+      3. trew_hip_add_gathered_device: one kernel over the gathered buffer adds every OTHER rank's rows into this rank's
+         device table (own slice skipped by index; ordered behind the collective on the device, by an event) -- the table
+         is the sum-merge structure, no dictionary is built anywhere;
+      4. rank 0 collects the merged rows; every rank's table then holds the global sums.
 
-    ctx: trew_amd.capi.TrewHip.  device: the torch device of ctx's GPU.  force_collectives issues the two
-    all_gathers even at world size 1 (the one-GPU test of the RCCL path).  Returns the merged rows on rank 0
-    (on every rank with rows_on_every_rank), None elsewhere."""
+    Why an all_gather and not the single all_reduce the north star names: the tables are sparse hash tables whose slot
+    layout differs per rank, so there is no common dense vector to reduce until the key sets have been exchanged --
+    which is the all_gather; once the rows are there the sum is local (SURVEY.md section 8(e) needs two collectives for
+    the same reason).  A rank with more rows than the slice holds shows in its header on every rank: nothing is added
+    anywhere and all ranks repeat the exchange with larger slices (same decision everywhere, no extra collective).
+
+    ctx: trew_amd.capi.TrewHip.  device: the torch device of ctx's GPU.  force_collectives issues the all_gather even
+    at world size 1 (the one-GPU test of the RCCL path).  Returns the merged rows on rank 0 (on every rank with
+    rows_on_every_rank), None elsewhere."""
     from .capi import ROW_DTYPE
 
     on = dist.is_available() and dist.is_initialized()
@@ -193,28 +203,24 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False, row
     rank = dist.get_rank(group)
     words = ROW_DTYPE.itemsize // 8
     cap = getattr(ctx, "_dev_rows_cap", 1 << 16)
+    on_gpu = torch.device(device).type == "cuda"
     while True:
-        buf = torch.empty((cap, words), dtype=torch.int64, device=device)
-        n = ctx.collect_device(buf.data_ptr(), cap)
-        if n <= cap:
+        bufs = getattr(ctx, "_exchange_bufs", None)
+        if bufs is None or bufs[0] != (cap, world, str(device)):
+            local = torch.zeros((1 + cap, words), dtype=torch.int64, device=device)
+            gathered = torch.empty((world * (1 + cap), words), dtype=torch.int64, device=device)
+            ctx._exchange_bufs = bufs = ((cap, world, str(device)), local, gathered)
+        _, local, gathered = bufs
+        n = ctx.collect_device(local[1:].data_ptr(), cap)  # synchronises the context's streams; rows beyond cap are not written
+        local[0, words - 1] = n  # header: the count sits where a row keeps its count (trew_hip_row.count)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        stream = torch.cuda.current_stream(device).cuda_stream if on_gpu else None
+        most = ctx.add_gathered_device(gathered.data_ptr(), world, rank, cap, stream)
+        if most <= cap:
             break
-        cap = ctx._dev_rows_cap = n + 4096
-    sizes = torch.zeros(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(sizes, torch.tensor([n], dtype=torch.int64, device=device), group=group)
-    sizes = [int(x) for x in sizes.cpu().tolist()]
-    n_max = max(max(sizes), 1)
-    local = torch.zeros((n_max, words), dtype=torch.int64, device=device)
-    local[:n] = buf[:n]
-    gathered = torch.empty((world * n_max, words), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(gathered, local, group=group)
-    torch.cuda.synchronize(device)
-    if not torch.equal(gathered[rank * n_max: rank * n_max + n], buf[:n]):
-        raise RuntimeError("all_gather returned this rank's own rows altered")
-    for r in range(world):
-        if r != rank and sizes[r]:
-            ctx.add_rows_device(gathered[r * n_max:].data_ptr(), sizes[r])
+        cap = ctx._dev_rows_cap = most + 4096  # some rank had more rows than a slice holds: nothing was added, go again
     if rows_on_every_rank or rank == 0:
-        ctx._collect_cap = max(getattr(ctx, "_collect_cap", 0), sum(sizes) + 1024)  # the merged table holds at most this many rows: one compaction
+        ctx._collect_cap = max(getattr(ctx, "_collect_cap", 0), world * most + 1024)  # the merged table holds at most this many rows: one compaction
         return ctx.collect_rows()
     return None  # this rank's device table holds the global sums as well; only rank 0 needs them on the host
 
