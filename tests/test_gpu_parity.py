@@ -557,6 +557,17 @@ def test_tiny_table_spills_but_stays_exact():
         assert t.collect() == want
 
 
+def _table_diff(got, want, limit=12):
+    """compact description of where two table sets differ (for assertion messages)"""
+    out = []
+    for name in want:
+        g, w = got.get(name, {}), want[name]
+        for key in sorted(set(g) | set(w)):
+            if g.get(key, 0) != w.get(key, 0):
+                out.append("%s k=%d %s: got %d want %d" % (name, key[0], O.int_to_four(key[1], key[0]), g.get(key, 0), w.get(key, 0)))
+    return "%d differing rows: %s" % (len(out), "; ".join(out[:limit]))
+
+
 def _tables_sum(a, b):
     out = {n: dict(a[n]) for n in a}
     for n in b:
@@ -658,7 +669,9 @@ def test_full_size_config5_share():
         assert sum(sum(v.values()) for v in whole.values()) > 125_000_000
         t.submit(t.device_uniform_batch(d, n, L), 1)
         t.wait(1)
-        assert t.collect() == {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        twice = t.collect()
+        want2 = {name: {k: 2 * c for k, c in whole[name].items()} for name in whole}
+        assert twice == want2, _table_diff(twice, want2)
         t.reset_tables()
         q = n // 5
         for i in range(5):
@@ -677,6 +690,31 @@ def test_full_size_config5_share():
     assert got == want
     buf0, _, _ = capi.synth_short_ascii(seed, 0, 64, L)
     assert bytes(buf[:64 * (L + 1)]) != bytes(buf0[:64 * (L + 1)])  # the offset really selects other reads
+
+
+def test_repeated_passes_are_identical():
+    """The prefilter's blocks pull chunks of reads from device counters and the exact kernel's waves pull survivors from a
+    sharded queue, so block / wave scheduling differs from launch to launch -- the tables and the number of survivors must
+    not.  40 passes over the same 12 M reads, slots alternating (a barrier missing at the end of the chunk queue once showed
+    up as a duplicated chunk in about one pass of twelve at 125 M reads, and only there)."""
+    n, L, seed = 12_000_000, 150, 20250218
+    stride = 3 * ((L + 31) // 32)
+    with T.TrewHip(mode=T.MODE_SHORT, n_slots=2, max_batch_reads=n, max_batch_words=16, table_log2_slots=20) as t:
+        d = t.malloc(n * stride * 4 + 64)
+        t.synth_short_device(seed, 5_000_000_000, n, L, d)  # read indices beyond 2^32 as well
+        ref = None
+        for rep in range(40):
+            t.reset_tables()
+            t.submit(t.device_uniform_batch(d, n, L), rep & 1)
+            t.wait(rep & 1)
+            got = (t.collect(), int(t.last_timing(rep & 1)[2]))
+            if ref is None:
+                ref = got
+                assert got[1] > 150_000
+            else:
+                assert got[1] == ref[1], (rep, got[1], ref[1])
+                assert got[0] == ref[0], (rep, _table_diff(got[0], ref[0]))
+        t.free(d)
 
 
 def test_full_size_config3_pairs():
@@ -775,6 +813,38 @@ def _fixed_len_reads(rnd, count, n):
         s += "".join(rnd.choice("ACGT") for _ in range(n - len(s)))
         out.append(s.encode())
     return out
+
+
+@pytest.mark.parametrize("n", [150, 151, 126, 190, 142, 66, 96])
+def test_uniform_fast_path_is_sound(n):
+    """Candidate masks of the prefilter's uniform-geometry fast path, per segment, against the oracle's class counts: every k
+    whose MAX/COUNT reaches LOW must be a candidate.  The lengths pick every k-range of the 3-word kernel (halves of 75:
+    first-64-windows subset bound for k < 12, one 64-bit container shift for 12 <= k <= 32; halves of 95: three mask words as
+    well; halves of 33/48: container and one-word ranges) and the 5-word kernel (n = 190 has halves of 95 -> 3 words, n = 126
+    a whole-read segment of 126 bases -> 5 words)."""
+    import random
+
+    rnd = random.Random(900 + n)
+    reads = _fixed_len_reads(rnd, 1200, n)
+    p = O.OracleParams()
+    words, offs, lens = capi.pack_reads(reads)
+    stride = 3 * ((n + 31) // 32)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 20) as t:
+        b = capi.Batch(words.ctypes.data, len(words), None, None, n, stride, len(reads), 0, 0)
+        cand = t.filter_masks(b, 3)
+    segs = [(0, n // 2, 5, min(n // 4, 32)), (n - (n + 1) // 2, n, 5, min(n // 4, 32))]
+    if n < 4 * 32:
+        segs.append((0, n, max(n // 4 + 1, 5), min(n // 2, 32)))
+    n_pass = 0
+    for i, r in enumerate(reads):
+        for slot, (a, e, kmin, kmax) in enumerate(segs):
+            if kmin > kmax:
+                continue
+            for k, (cnt, mx, _) in O.segment_stats(p, r[a:e], kmin, kmax).items():
+                if cnt and mx / cnt >= 0.5:
+                    n_pass += 1
+                    assert (int(cand[i, slot]) >> (k - 1)) & 1, (i, slot, k, r)
+    assert n_pass > 2000
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_FUZZ_SEEDS", "40"))))

@@ -40,6 +40,9 @@ struct DevBatch {
 };
 
 // the worklist is a plain array of unit indices (reads / pairs) that survived the prefilter
+// One counter block per launch (a slot owns two and alternates, trew_capi.cpp): word 0 = worklist size, then eight 32-word
+// lines: word 0 of line s = the exact kernel's queue head of shard s, word kChunkCounterWord = the prefilter's chunk counter of shard s.
+constexpr int kChunkCounterWord = 16;
 
 // words of DevTable::overflow (one 64-byte line of device counters, cleared by trew_hip_reset_tables)
 enum {
@@ -203,6 +206,24 @@ TREW_HD inline Segment get_segment(int mode, int slot, u32 n1, u32 n2, int MIN_M
         s.valid = true;
     }
     return s;
+}
+
+// Windows the prefilter's uniform-geometry fast path LOOKS AT for (segment length L, k) in an nw-word kernel: all COUNT = L-k+1
+// of them, except that the 3-word kernel stops at the first 64 when there are 65..kUniSubsetMax (a sound subset bound, see
+// filter_k_uni).  fill_thresholds (host) and the kernel both go by this function.
+#ifndef TREW_AB_NO_SUBSET
+constexpr int kUniSubsetMax = 72;
+#else
+constexpr int kUniSubsetMax = 64;  // A/B builds: no subset range
+#endif
+TREW_HD inline int uni_windows(int nw, int L, int k) {
+    const int W = L - k + 1;
+#ifdef TREW_AB_NO_CONTAINER
+    (void) nw;
+    return W;
+#else
+    return (nw == 3 && W > 64 && W <= kUniSubsetMax) ? 64 : W;
+#endif
 }
 
 TREW_HD inline int mode_slots(int mode) {

@@ -73,6 +73,12 @@ int pick_nw(u32 max_seg_len) {
 // Host side (single-precision multiply, the same IEEE operation the general path performs on the device).
 void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
     const int nslots = mode_slots(P.mode);
+    u32 max_seg = 0;  // the kernel instantiation launch_filter picks for this geometry
+    for (int slot = 0; slot < nslots; slot++) {
+        const Segment sg = get_segment(P.mode, slot, uniform_length, uniform_length, P.min_mer, P.max_mer, P.slice_len);
+        if (sg.valid) max_seg = std::max(max_seg, sg.len);
+    }
+    const int nw = pick_nw(max_seg);
     for (int slot = 0; slot < kMaxSlots; slot++) {
         const Segment sg = get_segment(P.mode, slot, uniform_length, uniform_length, P.min_mer, P.max_mer, P.slice_len);
         for (int k = 1; k <= kThrRow; k++) {
@@ -82,8 +88,10 @@ void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
             th.y = -1;
             if (slot < nslots && sg.valid && W > 0) {
                 const volatile float prod = (float) W * P.lowf;  // volatile: no contraction, no extended precision
-                th.x = (int) floorf(prod) + 1;
-                th.y = W - th.x;
+                // a class needs ithr of the W windows; of the Weff windows the kernel looks at it then has at least ithr - (W - Weff)
+                const int Weff = uni_windows(nw, (int) sg.len, k);
+                th.x = (int) floorf(prod) + 1 - (W - Weff);
+                th.y = Weff - th.x;
             }
             table[slot * kThrRow + k - 1] = th;
         }
