@@ -62,9 +62,22 @@ def usable_cores():
 
 
 def committed_profile(n, L):
-    """HBM traffic and VALU issue figures of both kernels from the committed rocprofv3 PMC run of this same
-    command (profiles/<round>/pmc_summary_final.csv + kernel_stats_final.csv, written by profiles/summarize.py).
-    Returns (traffic_by_kernel, valu_by_kernel, round) or (None, None, None) when the configuration differs."""
+    """HBM traffic and VALU issue accounting of both kernels from the committed rocprofv3 PMC runs of this same command
+    (profiles/<round>/pmc_summary_final.csv + kernel_stats_final_serial.csv, written by profiles/summarize.py), the static
+    instruction mix of the hot loops (profiles/<round>/hot_loops.json, tools/isa_loops.py on the ISA of the build) and the
+    measured issue cost of the two VALU classes (profiles/valu_rate.json, tools/valu_rate.hip on the box).
+    Returns (traffic_by_kernel, valu_by_kernel, round) or (None, None, None) when the configuration differs.
+
+    Per kernel:
+      issue_frac_2cyc   SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles): the share of the naive peak of one wave64
+                        VALU instruction per SIMD-32 every 2 cycles (MI355X_MICROARCH.md)
+      class_weighted    the same with what the instructions really cost: the hot loops' static split into full-rate ops
+                        (xor / and / add / sub / mov / bitop3: 2.26 cycles per wave-instruction measured) and half-rate ops
+                        (shifts, v_bcnt, v_alignbit, compares, v_max3, 64-bit shifts: 4.15 cycles) applied to the dynamic
+                        instruction count: valu_issue = the share of the kernel's SIMD cycles in which a VALU instruction
+                        occupies the pipe (half_rate / full_rate: its two parts), not_valu_issue = the rest (scalar
+                        instructions of the same waves, waits, barriers, the tail of the launch)
+    Kernel cycles use the clock the chip held in the profiled run (GRBM_GUI_ACTIVE / 8 XCDs / kernel time)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if tj["config"] != {"reads_per_gpu": n, "read_len": L}:
@@ -81,9 +94,10 @@ def committed_profile(n, L):
             for kern in ("filter_kernel", "exact_kernel"):
                 if kern in r["kernel"]:
                     cnt.setdefault(kern, {})[r["counter"]] = float(r["avg_per_dispatch"])
-        # durations of the kernels ALONE on the device (the PMC passes serialise dispatches): the one-stream trace when
-        # the round has one, else the round's only trace
-        stats = os.path.join(prof, "kernel_stats_serial.csv")
+        # durations of the kernels ALONE on the device (the PMC passes serialise dispatches): the one-stream trace
+        stats = os.path.join(prof, "kernel_stats_final_serial.csv")
+        if not os.path.exists(stats):
+            stats = os.path.join(prof, "kernel_stats_serial.csv")
         if not os.path.exists(stats):
             stats = os.path.join(prof, "kernel_stats_final.csv")
         for r in csv.DictReader(open(stats)):
@@ -91,23 +105,44 @@ def committed_profile(n, L):
                 if kern in r["Name"]:
                     dur[kern] = float(r["AverageNs"])
         rates = json.load(open(os.path.join(ROOT, "profiles", "valu_rate.json")))
+        c_full, c_half = rates["classes"]["full_rate"], rates["classes"]["half_rate"]
+        try:
+            hot = json.load(open(os.path.join(prof, "hot_loops.json")))
+        except (OSError, ValueError):
+            hot = {}
         for kern in cnt:
             c = cnt[kern]
-            if "SQ_ACTIVE_INST_VALU" not in c or kern not in dur:
+            if "SQ_INSTS_VALU" not in c or kern not in dur:
                 continue
-            simd_cycles = N_SIMD * dur[kern] * 1e-9 * CLOCK_HZ
-            active = c["SQ_ACTIVE_INST_VALU"] * 4.0  # rocprof's VALUBusy definition
-            valu[kern] = {
-                "insts_valu": round(c.get("SQ_INSTS_VALU", 0)),
+            clock = c["GRBM_GUI_ACTIVE"] / 8.0 / (dur[kern] * 1e-9) if "GRBM_GUI_ACTIVE" in c else CLOCK_HZ
+            simd_cycles = N_SIMD * dur[kern] * 1e-9 * clock
+            entry = {
+                "insts_valu": round(c["SQ_INSTS_VALU"]),
                 "insts_salu": round(c.get("SQ_INSTS_SALU", 0)),
                 "profiled_launch_ms": round(dur[kern] * 1e-6, 4),
-                "issue_frac": round(active / simd_cycles, 3),
-                "cycles_per_valu_inst": round(active / c["SQ_INSTS_VALU"], 2) if c.get("SQ_INSTS_VALU") else None,
+                "clock_ghz": round(clock * 1e-9, 3),
+                "issue_frac_2cyc": round(c["SQ_INSTS_VALU"] * 2.0 / simd_cycles, 3),
+                "waves_resident_avg_per_simd": round(c["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles, 2) if "SQ_WAVE_CYCLES" in c else None,
             }
-        valu["cycles_per_inst_by_class"] = rates["cycles_per_wave_inst"]
-        valu["source"] = "profiles/%s/pmc_summary_final.csv (counters), %s (durations alone on the device); profiles/valu_rate.json (tools/valu_rate.hip on the box)" % (
-            rnd, os.path.basename(stats))
-    except (OSError, KeyError, ValueError):
+            h = hot.get(kern)
+            if h:
+                share = h["half_rate_share_of_valu_insts"]
+                half = c["SQ_INSTS_VALU"] * share * c_half / simd_cycles
+                full = c["SQ_INSTS_VALU"] * (1.0 - share) * c_full / simd_cycles
+                entry["class_weighted"] = {
+                    "half_rate_share_of_valu_insts": round(share, 3),
+                    "half_rate_issue": round(half, 3),
+                    "full_rate_issue": round(full, 3),
+                    "valu_issue": round(half + full, 3),
+                    "not_valu_issue": round(1.0 - half - full, 3),
+                    "salu_per_valu_inst": round(c.get("SQ_INSTS_SALU", 0) / c["SQ_INSTS_VALU"], 3),
+                    "mix_from": h["from"],
+                }
+            valu[kern] = entry
+        valu["cycles_per_wave_inst"] = {"full_rate": c_full, "half_rate": c_half}
+        valu["source"] = "profiles/%s/pmc_summary_final.csv (counters), %s (durations alone on the device), profiles/%s/hot_loops.json (tools/isa_loops.py), profiles/valu_rate.json (tools/valu_rate.hip on the box)" % (
+            rnd, os.path.basename(stats), rnd)
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         valu = {}
     return traffic, (valu or None), rnd
 
@@ -227,6 +262,70 @@ def oracle_check(w, args, O, cores):
     return got == want, what, bases, cpu_dt, used
 
 
+def write_fastq(path, capi, n, L, chunk=1_000_000):
+    """n synthetic reads of the bench workload as a plain FASTQ file (records "@r / seq / + / quality", large writes)."""
+    import numpy as np
+
+    with open(path, "wb") as f:
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            buf, _, _ = capi.synth_short_ascii(SEED, lo, m, L)
+            b = np.frombuffer(buf, dtype=np.uint8).reshape(m, L + 1)
+            rec = np.zeros((m, 3 + (L + 1) + 2 + (L + 1)), dtype=np.uint8)
+            rec[:, 0:3] = np.frombuffer(b"@r\n", dtype=np.uint8)
+            rec[:, 3:3 + L + 1] = b
+            rec[:, 4 + L:6 + L] = np.frombuffer(b"+\n", dtype=np.uint8)
+            rec[:, 6 + L:6 + 2 * L] = ord("I")
+            rec[:, 6 + 2 * L] = ord("\n")
+            rec.tofile(f)
+
+
+def end_to_end(capi, args, cores):
+    """The `trew` binary on a FASTQ file of the same workload in page cache: FASTQ text -> CSV, PCIe-inclusive.  Never the
+    bench `value`; reported beside it.  Returns a dict or None (no writable scratch directory)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    trew = os.path.join(ROOT, "trew_amd", "bin", "trew")
+    if not os.path.exists(trew):
+        return None
+    n = args.e2e_reads
+    need = n * (2 * args.read_len + 8) * 1.05
+    base = None
+    for cand in ("/dev/shm", tempfile.gettempdir()):
+        try:
+            if os.path.isdir(cand) and shutil.disk_usage(cand).free > need * 1.2:
+                base = cand
+                break
+        except OSError:
+            continue
+    if base is None:
+        return None
+    d = tempfile.mkdtemp(prefix="trew_e2e_", dir=base)
+    try:
+        path = os.path.join(d, "e2e.fastq")
+        write_fastq(path, capi, n, args.read_len)
+        threads = max(2, cores)
+        best = None
+        for rep in range(2):  # the first run also pays for the module load and the page-cache warm-up of the mapping
+            r = subprocess.run([trew, "short", str(args.min_mer), str(args.max_mer), path, "-t", str(threads), "--stats"], capture_output=True, text=True, timeout=600)
+            m = re.search(r"([0-9.]+) s, ([0-9.]+) Gbases/s end-to-end \(decode \+ pack \+ scan; ([^,]+),", r.stderr)
+            if r.returncode != 0 or not m:
+                return {"error": (r.stderr or "")[-300:]}
+            if best is None or float(m.group(2)) > best["gbases_s"]:
+                pw = re.search(r"newline scan \+ line chain ([0-9.]+), wait for the slot ([0-9.]+), pack ([0-9.]+), submit ([0-9.]+)", r.stderr)
+                phases = dict(zip(("scan", "wait_slot", "pack_or_copy", "submit"), (float(x) for x in pw.groups()))) if pw else {}
+                best = {"gbases_s": float(m.group(2)), "seconds": float(m.group(1)), "threads": threads, "reads": n, "reader": m.group(3).strip(),
+                        "worker_seconds": phases, "bound_by": ("host: " + max(phases, key=phases.get)) if phases else None,
+                        "input": "plain FASTQ, %.1f GB of text in page cache (%s), CSV to a pipe" % (os.path.getsize(path) / 1e9, base),
+                        "note": "PCIe-inclusive, FASTQ text to CSV; never the bench value"}
+        return best
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +340,8 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=30_000, help="pairs of config 3 checked against the oracle")
     ap.add_argument("--cpu-long-reads", type=int, default=5_000, help="reads of config 4 checked against the oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: do not run the `trew` binary on a FASTQ file of the workload")
+    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end FASTQ file (4.9 GB of text at 16 M x 150 bp)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1, --mode short only: do not time configs 3 and 4")
     ap.add_argument("--other-steps", type=int, default=0, help="passes per other config (default: min(steps, 10))")
     ap.add_argument("--streams", type=int, default=2, help="batch slots (HIP streams) the passes alternate between")
@@ -365,14 +466,15 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
+                "slot_cycle_ms": round(f_avg + e_avg, 4),  # one slot runs its prefilter then its exact kernel: with S slots a step takes >= slot_cycle_ms / S
                 "serial_launch_ms": {"filter_kernel": round(s_f, 4), "exact_kernel": round(s_e, 4)},
                 "frac_serial": round(alg_bytes / (s_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "valu": valu,
-                "valu_busy": (valu or {}).get(dom, {}).get("issue_frac"),
+                "valu_busy": ((valu or {}).get(dom, {}).get("class_weighted") or {}).get("valu_issue"),
                 "note": "integer-issue bound, not HBM bound (SURVEY 8(d)). avg_launch_ms: HIP events over the timed region, where the %d slots overlap "
                         "(a kernel shares the SIMDs with the other slot's kernel, so its own launch is longer than alone); serial_launch_ms: the same "
                         "kernels alone on one stream, measured in this run outside the timed region.  valu: SQ counters of the committed rocprofv3 PMC "
-                        "run of this command (profiles/%s), issue_frac = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs x kernel cycles at 2.4 GHz).  %.3g (window,k) "
+                        "runs of this command (profiles/%s): issue_frac_2cyc = SQ_INSTS_VALU x 2 / SIMD cycles, class_weighted = the same with the measured cost of full-rate (2.26 cycles) and half-rate (4.15 cycles) instructions, see bench.py::committed_profile.  %.3g (window,k) "
                         "evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
                         % (max(1, args.streams), prof_round or "none for this configuration", evals / (ms_per_step * 1e-3),
                            evals / (ms_per_step * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),
@@ -436,6 +538,11 @@ def main():
             others.append(entry)
         out["other_configs"] = others
 
+    if rank == 0 and world == 1 and args.mode == "short" and not args.no_e2e and not args.no_cpu:
+        try:
+            out["e2e"] = end_to_end(capi, args, usable_cores())
+        except Exception as ex:  # the end-to-end leg must never take the bench line down
+            out["e2e"] = {"error": repr(ex)[:300]}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

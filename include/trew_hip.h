@@ -76,6 +76,8 @@ typedef struct {
     uint64_t max_batch_reads; /* capacity of one slot, reads (pairs count as two)             */
     uint32_t table_log2_slots;/* device count table: 2^table_log2_slots entries (>= 12)       */
     uint32_t flags;           /* TREW_FLAG_*                                                  */
+    uint64_t max_batch_ascii_bytes; /* ABI 3: capacity of one slot for trew_hip_submit_ascii (sequence bytes + 12 B per
+                                 read of index arrays); 0 = text batches are not used            */
 } trew_hip_params;
 
 /* Replaces QueueData / PairQueueData + LocationVector (kmer.h:73, 93-103): one
@@ -97,6 +99,26 @@ typedef struct {
     int32_t on_device;
     int32_t max_length;       /* on_device + lengths only: longest read of the batch (0 = unknown) */
 } trew_hip_batch;
+
+/* The same chunk as TEXT, closest to what the reference's consumers pop (QueueData: a char buffer plus the [st, nd]
+ * locations of the sequence lines, kmer.h:93-96): the bytes of the sequence lines only, in one pinned host buffer, and the
+ * DEVICE applies codes[] (kmer.cpp:14-31) -- a pack kernel in front of the prefilter -- so that host threads only locate
+ * lines and copy bytes.  Two shapes:
+ *   uniform  byte_offsets == lengths == word_offsets == NULL: read r is bases[r * uniform_length .. + uniform_length)
+ *   ragged   read r is bases[byte_offsets[r] .. + lengths[r]); word_offsets[r] = 3 * sum_{q<r} ceil(lengths[q] / 32), the
+ *            place of its first packed triple (a running sum the host has anyway)
+ * When the arrays lie back to back as [word_offsets][byte_offsets][lengths][bases] the batch is shipped with one copy.
+ * The caller keeps ownership until trew_hip_wait(slot).  n_bytes + 12 * n_reads <= max_batch_ascii_bytes. */
+typedef struct {
+    const char *bases;
+    uint64_t n_bytes;
+    const uint32_t *byte_offsets;
+    const uint32_t *lengths;
+    const uint32_t *word_offsets;
+    uint32_t uniform_length;
+    uint32_t reserved;
+    uint64_t n_reads;         /* pair mode: reads 2i and 2i+1 are mates                       */
+} trew_hip_ascii_batch;
 
 /* one (k, word) -> count row; word = the 2k-bit k-mer, first base most
  * significant (KmerSeq, kmer.h:77); word_hi is 0 for k <= 32. */
@@ -122,6 +144,12 @@ const char *trew_hip_last_error(const trew_hip_ctx *ctx);
  * asynchronously copies the batch (unless on_device), runs the prefilter and
  * the exact kernel on the slot's stream, accumulating into the device tables. */
 int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot);
+/* trew_hip_submit for a chunk of text: copies the batch, packs it on the device (bit planes identical to
+ * trew_pack_reads, word for word) and runs the two kernels on the packed reads. */
+int trew_hip_submit_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *batch, int slot);
+/* Diagnostic: packs `batch` on the device exactly as trew_hip_submit_ascii does and copies the packed words back
+ * (words_cap words available; *n_words = words the batch packs to).  Tests compare them with trew_pack_reads. */
+int trew_hip_pack_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *batch, uint32_t *words, uint64_t words_cap, uint64_t *n_words);
 /* Blocks until the slot's work is done (tasks.wait, kmer.cpp:1323-1325). */
 int trew_hip_wait(trew_hip_ctx *ctx, int slot);
 

@@ -14,7 +14,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-other-configs ${BENCH_EXTRA:-}"
+BENCH="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-other-configs --no-e2e ${BENCH_EXTRA:-}"
 for s in $SETS; do
   case $s in
     trace)  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 ;;

@@ -288,6 +288,52 @@ def test_filter_masks_between_submits_leaves_the_queue_counters_clean():
         assert t.collect() == want
 
 
+def test_device_pack_matches_host_pack():
+    """trew_hip_submit_ascii: codes[] (kmer.cpp:14-31) applied by a kernel.  The packed words must equal trew_pack_reads word
+    for word -- every byte value, either case, reads that start at every byte alignment and end at every position of a
+    triple, empty reads -- and the tables of a text batch must equal those of the host-packed batch."""
+    import random
+
+    rnd = random.Random(12)
+    reads = [bytes(range(256)), bytes(range(255, -1, -1)), b"", b"A", b"acgtnACGTN" * 13, b"N" * 33, b"T" * 32, b"G" * 31]
+    for n in list(range(1, 70)) + [95, 96, 97, 127, 128, 129, 150, 151, 250, 999, 1000]:
+        reads.append("".join(rnd.choice("ACGTacgtNn.*\r") if rnd.random() < 0.1 else rnd.choice("ACGT") for _ in range(n)).encode())
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 3000, 150)
+    synth = [buf[s:e + 1] for s, e in zip(st, nd)]
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=1 << 14, max_batch_words=1 << 20, max_batch_ascii_bytes=1 << 22) as t:
+        for contiguous in (True, False):
+            got = t.pack_ascii(t.ascii_batch(reads, contiguous=contiguous))
+            want, _, _ = capi.pack_reads(reads)
+            assert got.shape == want.shape and (got == want).all(), np.nonzero(got != want)[0][:10]
+        got = t.pack_ascii(t.ascii_batch(synth, uniform=150))
+        want, _, _ = capi.pack_reads(synth)
+        assert (got == want).all()
+        # tables: text batch (ragged and uniform) == host-packed batch == oracle
+        short = [r for r in reads if len(r) <= 1000] + synth
+        want_t = O.run_short(O.OracleParams(), short)
+        t.submit_ascii(t.ascii_batch(short))
+        t.wait()
+        assert t.collect() == want_t
+        t.reset_tables()
+        t.submit_ascii(t.ascii_batch(synth, uniform=150), 1)
+        t.wait(1)
+        assert t.collect() == O.run_short(O.OracleParams(), synth)
+        with pytest.raises(T.TrewHipError):
+            t.submit_ascii(t.ascii_batch([b"A" * 1001]))
+    with pytest.raises(T.TrewHipError, match="max_batch_ascii_bytes"):
+        with T.TrewHip(mode=T.MODE_SHORT) as t:
+            t.submit_ascii(t.ascii_batch([b"ACGT" * 10]))
+    # pair mode: reads 2i, 2i+1 are mates
+    b1, b2, st, nd = capi.synth_pair_ascii(20250218, 0, 4000, 150)
+    inter = []
+    for s_, e_ in zip(st, nd):
+        inter += [b1[s_:e_ + 1], b2[s_:e_ + 1]]
+    with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=1 << 14, max_batch_words=1 << 20, max_batch_ascii_bytes=1 << 22) as t:
+        t.submit_ascii(t.ascii_batch(inter))
+        t.wait()
+        assert t.collect() == O.run_pair(O.OracleParams(), inter[0::2], inter[1::2])
+
+
 def test_empty_and_tiny_batches():
     with T.TrewHip(mode=T.MODE_SHORT) as t:
         t.submit_reads([])

@@ -4,9 +4,10 @@
 //   tools/valu_rate [waves_per_simd = 8] [json]
 // Every op is emitted through inline asm so that the compiler cannot fold the chains (an earlier version of this tool let
 // LLVM simplify the xor chain and reported an impossible 1.5 cycles).  Eight independent chains per wave, `waves_per_simd`
-// waves on every SIMD.  Cycles are SHADER cycles measured in the kernel (s_memtime around the loop, median over waves), so
-// the figures do not depend on the clock the chip happens to hold; the clock itself is reported as
-// delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+// waves on every SIMD.  The figure reported is SIMD cycles per wave-instruction = kernel time x clock / instructions per SIMD,
+// with the clock the chip actually held during that kernel: delta s_memtime / delta s_memrealtime x 100 MHz, median over
+// waves (MI355X_MICROARCH.md, DVFS item 6) -- 1.9 to 2.4 GHz depending on the op.  (The duration of the MEDIAN wave is
+// printed too but is not a throughput: issue arbitration favours older waves, which finish at 64 % of the kernel's time.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -170,8 +171,8 @@ int main(int argc, char **argv) {
         std::nth_element(cyc.begin(), cyc.begin() + waves / 2, cyc.end());
         std::nth_element(clk.begin(), clk.begin() + waves / 2, clk.end());
         const double winstr_per_wave = (double) iters * 64;  // 8 rounds of 8 instructions per iteration
-        // wps waves share one SIMD: SIMD cycles per wave-instruction = wave cycles / (instructions x waves on the SIMD)
-        const double per_inst = cyc[waves / 2] / (winstr_per_wave * wps);
+        // wps waves share one SIMD: SIMD cycles per wave-instruction = kernel cycles / instructions issued on the SIMD
+        const double per_inst = (double) ms * 1e-3 * clk[waves / 2] / (winstr_per_wave * wps);
         clock_sum += clk[waves / 2];
         if (json)
             printf("%s\"%s\": %.2f", op ? ", " : "", kNames[op], per_inst);
@@ -179,6 +180,6 @@ int main(int argc, char **argv) {
             printf("%-48s %.3f ms  %.2f SIMD cycles per wave-instruction  (in-kernel clock %.2f GHz; first wave start to last wave end %.3f ms, wave starts spread over %.3f ms, median wave %.3f ms)\n",
                    kNames[op], ms, per_inst, clk[waves / 2] * 1e-9, span_ms, start_spread_ms, cyc[waves / 2] / clk[waves / 2] * 1e3);
     }
-    if (json) printf("}, \"clock_ghz\": %.3f, \"source\": \"tools/valu_rate.hip: s_memtime around 192 000 instructions per wave, %d waves per SIMD, median over waves\"}\n", clock_sum / N_OPS * 1e-9, wps);
+    if (json) printf("}, \"clock_ghz\": %.3f, \"source\": \"tools/valu_rate.hip: kernel time x in-kernel clock / instructions per SIMD, 192 000 instructions per wave, %d waves per SIMD\"}\n", clock_sum / N_OPS * 1e-9, wps);
     return 0;
 }

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
     "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
     "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
-    "trew_hip_add_gathered_device", "trew_hip_debug_counters",
+    "trew_hip_add_gathered_device", "trew_hip_debug_counters", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
 )
 DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide")
 
@@ -43,6 +43,7 @@ class Params(C.Structure):
         ("slice_length", C.c_int32), ("mode", C.c_int32), ("device", C.c_int32), ("n_slots", C.c_int32),
         ("max_batch_words", C.c_uint64), ("max_batch_reads", C.c_uint64),
         ("table_log2_slots", C.c_uint32), ("flags", C.c_uint32),
+        ("max_batch_ascii_bytes", C.c_uint64),
     ]
 
 
@@ -52,6 +53,14 @@ class Batch(C.Structure):
         ("offsets", C.c_void_p), ("lengths", C.c_void_p),
         ("uniform_length", C.c_uint32), ("uniform_stride", C.c_uint32),
         ("n_reads", C.c_uint64), ("on_device", C.c_int32), ("max_length", C.c_int32),
+    ]
+
+
+class AsciiBatch(C.Structure):
+    _fields_ = [
+        ("bases", C.c_void_p), ("n_bytes", C.c_uint64),
+        ("byte_offsets", C.c_void_p), ("lengths", C.c_void_p), ("word_offsets", C.c_void_p),
+        ("uniform_length", C.c_uint32), ("reserved", C.c_uint32), ("n_reads", C.c_uint64),
     ]
 
 
@@ -100,6 +109,8 @@ def load():
     lib.trew_hip_last_error.restype = C.c_char_p
     lib.trew_hip_submit.argtypes = [vp, C.POINTER(Batch), i32]
     lib.trew_hip_wait.argtypes = [vp, i32]
+    lib.trew_hip_submit_ascii.argtypes = [vp, C.POINTER(AsciiBatch), i32]
+    lib.trew_hip_pack_ascii.argtypes = [vp, C.POINTER(AsciiBatch), vp, u64, C.POINTER(u64)]
     lib.trew_hip_collect.argtypes = [vp, i32, C.POINTER(Row), u64, C.POINTER(u64)]
     lib.trew_hip_reset_tables.argtypes = [vp]
     lib.trew_hip_add_rows.argtypes = [vp, C.POINTER(Row), u64]
@@ -202,11 +213,11 @@ class TrewHip:
     """One device context: init / submit / wait / collect."""
 
     def __init__(self, mode=MODE_SHORT, min_mer=5, max_mer=32, low=0.5, high=0.8, slice_length=150, device=0,
-                 n_slots=2, max_batch_words=1 << 22, max_batch_reads=1 << 18, table_log2_slots=20, flags=0):
+                 n_slots=2, max_batch_words=1 << 22, max_batch_reads=1 << 18, table_log2_slots=20, flags=0, max_batch_ascii_bytes=0):
         self.lib = load()
         flags |= int(os.environ.get("TREW_EXTRA_FLAGS", "0"))  # e.g. 32 = FLAG_DEBUG_POISON_LDS for a whole test run
         self.params = Params(min_mer, max_mer, low, high, slice_length, mode, device, n_slots, max_batch_words,
-                             max_batch_reads, table_log2_slots, flags)
+                             max_batch_reads, table_log2_slots, flags, max_batch_ascii_bytes)
         self.ctx = C.c_void_p()
         rc = self.lib.trew_hip_init(C.byref(self.params), C.byref(self.ctx))
         if rc != 0:
@@ -248,6 +259,46 @@ class TrewHip:
     def device_uniform_batch(self, d_words, n_reads, read_len):
         stride = 3 * ((read_len + 31) // 32)
         return Batch(d_words, n_reads * stride, None, None, read_len, stride, n_reads, 1, read_len)
+
+    def ascii_batch(self, reads, contiguous=True, uniform=None):
+        """Text batch of the reads (bytes objects): the sequence bytes back to back + word/byte offsets + lengths, laid out
+        [word_offsets][byte_offsets][lengths][bases] in one buffer when contiguous.  uniform=L: no arrays, every read has L bases."""
+        reads = [r.encode() if isinstance(r, str) else bytes(r) for r in reads]
+        n = len(reads)
+        text = np.frombuffer(b"".join(reads) + b"\0" * 8, dtype=np.uint8)
+        n_bytes = len(text) - 8
+        if uniform is not None:
+            assert all(len(r) == uniform for r in reads)
+            b = AsciiBatch(text.ctypes.data, n_bytes, None, None, None, uniform, 0, n)
+            b._keep = (text,)
+            return b
+        lens = np.array([len(r) for r in reads], dtype=np.uint32)
+        boff = np.zeros(n, dtype=np.uint32)
+        woff = np.zeros(n, dtype=np.uint32)
+        if n:
+            boff[1:] = np.cumsum(lens[:-1], dtype=np.uint64).astype(np.uint32)
+            woff[1:] = np.cumsum(3 * ((lens[:-1].astype(np.uint64) + 31) // 32)).astype(np.uint32)
+        if contiguous:
+            buf = np.concatenate([woff.view(np.uint8), boff.view(np.uint8), lens.view(np.uint8), text])
+            base = buf.ctypes.data
+            b = AsciiBatch(base + 12 * n, n_bytes, base + 4 * n, base + 8 * n, base, 0, 0, n)
+            b._keep = (buf,)
+            return b
+        b = AsciiBatch(text.ctypes.data, n_bytes, boff.ctypes.data, lens.ctypes.data, woff.ctypes.data, 0, 0, n)
+        b._keep = (text, boff, lens, woff)
+        return b
+
+    def submit_ascii(self, batch, slot=0):
+        self._keep[slot] = batch
+        self._chk(self.lib.trew_hip_submit_ascii(self.ctx, C.byref(batch), slot), "trew_hip_submit_ascii")
+
+    def pack_ascii(self, batch):
+        """The packed words the device makes of a text batch (diagnostic: must equal pack_reads())."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_pack_ascii(self.ctx, C.byref(batch), None, 0, C.byref(n)), "trew_hip_pack_ascii")
+        words = np.zeros(max(int(n.value), 1), dtype=np.uint32)
+        self._chk(self.lib.trew_hip_pack_ascii(self.ctx, C.byref(batch), words.ctypes.data, len(words), C.byref(n)), "trew_hip_pack_ascii")
+        return words[: int(n.value)]
 
     def submit(self, batch, slot=0):
         self._keep[slot] = batch

@@ -167,7 +167,8 @@ struct Worker {
     // ships with a single copy (include/trew_hip.h, trew_hip_batch)
     uint32_t *h_buf = nullptr;
     std::vector<uint32_t> tmp_off, tmp_len;  // block reader: offsets / lengths until the batch is closed
-    uint64_t words_cap = 0, reads_cap = 0;
+    uint64_t words_cap = 0, reads_cap = 0, text_cap = 0;
+    std::vector<uint32_t> tmp_woff;  // text batches: word offset of every read (running sum of the packed sizes)
     uint64_t reads = 0, bases = 0, submits = 0;
     double t_scan = 0, t_wait = 0, t_pack = 0, t_submit = 0, t_pressure = 0;  // seconds per phase, for --stats (t_pressure is part of t_submit)
     std::vector<int64_t> st, nd;      // block-parallel reader: sequence lines of the current block
@@ -191,6 +192,7 @@ struct Scanner {
     std::mutex pending_mu;
     ResultMapData pending;
     std::atomic<uint64_t> drains{0};
+    double t_map = 0, t_workers = 0, t_unmap = 0, t_collect = 0;  // --stats: wall seconds of the block-parallel reader's stages
 };
 
 [[noreturn]] static void hip_die(trew_hip_ctx *ctx, const char *what) {
@@ -211,6 +213,8 @@ Scanner *scanner_create(const Config &cfg, int mode) {
     // serial reader: one 4 MiB chunk per mate; block reader: kSubmitBytes of text per batch plus the line that ends in a
     // block but started before it; every read may waste up to one triple of padding
     const uint64_t words_cap = 3ull * ((uint64_t) (kSubmitBytes + 2 * LENGTH) / 32 + reads_cap) + 64;
+    // text batches of the block-parallel reader (the device packs): the sequence bytes of a batch + 12 B of index arrays per read
+    const uint64_t text_cap = (uint64_t) (kSubmitBytes + 2 * LENGTH) + 12ull * reads_cap;
     std::vector<int> slots_on_dev((size_t) ndev, 0);
     for (int w = 0; w < n_workers; w++) slots_on_dev[(size_t) (w % ndev)]++;
     for (int d = 0; d < ndev; d++) {
@@ -227,6 +231,7 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         p.max_batch_words = words_cap;
         p.max_batch_reads = reads_cap;
         p.table_log2_slots = (uint32_t) cfg.table_log2_slots;
+        p.max_batch_ascii_bytes = cfg.host_pack ? 0 : text_cap;
         p.flags = TREW_FLAG_NO_TIMING;  // ~10^4 small batches a second: every HIP call per batch counts
         trew_hip_ctx *c = nullptr;
         if (trew_hip_init(&p, &c) != 0) die(trew_hip_last_error(nullptr));
@@ -241,7 +246,8 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         wk.words_cap = words_cap;
         wk.reads_cap = reads_cap;
         trew_hip_ctx *c = s->dev[(size_t) wk.dev_index]->ctx;
-        if (trew_hip_host_alloc(c, (words_cap + 2 * reads_cap) * 4, (void **) &wk.h_buf)) hip_die(c, "pinned allocation");
+        wk.text_cap = text_cap;
+        if (trew_hip_host_alloc(c, std::max<uint64_t>((words_cap + 2 * reads_cap) * 4, text_cap + 64), (void **) &wk.h_buf)) hip_die(c, "pinned allocation");
         s->workers.push_back(std::move(wk));
     }
     return s;
@@ -327,6 +333,28 @@ static void submit_packed(Scanner *s, Worker *w, uint32_t *h_words, uint32_t *h_
     if (trew_hip_submit(c, &b, w->slot)) hip_die(c, "trew_hip_submit");
 }
 
+// the same for a batch of TEXT (sequence bytes + index arrays, see trew_hip_ascii_batch): the device packs
+static void submit_text(Scanner *s, Worker *w, const trew_hip_ascii_batch &b, uint64_t bases) {
+    Device *d = s->dev[(size_t) w->dev_index].get();
+    trew_hip_ctx *c = d->ctx;
+    w->bases += bases;
+    w->reads += b.n_reads;
+    if (b.n_reads == 0) return;
+    w->submits++;
+    const auto tp0 = std::chrono::steady_clock::now();
+    const bool pressed = under_pressure(c);
+    w->t_pressure += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+    if (pressed) {
+        std::unique_lock<std::shared_mutex> lk(d->drain_mu);  // waits for running submits, blocks new ones
+        if (under_pressure(c)) {                              // nobody drained in the meantime
+            drain_device(s, d);
+            s->drains++;
+        }
+    }
+    std::shared_lock<std::shared_mutex> lk(d->drain_mu);
+    if (trew_hip_submit_ascii(c, &b, w->slot)) hip_die(c, "trew_hip_submit_ascii");
+}
+
 // the consumer: buffer_task* (kmer.cpp:80-985) with the scan itself moved to the device
 static void worker_loop(Scanner *s, Worker *w, ChunkQueue *q) {
     trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
@@ -339,7 +367,7 @@ static void worker_loop(Scanner *s, Worker *w, ChunkQueue *q) {
         if (!ch->located) {
             // the newline that makes num & 3 == 2 closes a sequence line (read_fastq_thread, kmer.cpp:1002-1011); a chunk
             // starts at a line start or, after a carry-over, at the start of a sequence line
-            if (w->nl.size() < (size_t) LENGTH) w->nl.resize((size_t) LENGTH);
+            if (w->nl.size() < (size_t) LENGTH + 2) w->nl.resize((size_t) LENGTH + 2);  // + 2: scan_newlines stores two slots ahead
             const size_t cnt = scan_newlines(ch->buffer1, (size_t) ch->total, w->nl.data());
             const bool long_mode = s->mode == TREW_MODE_LONG;
             for (size_t j = (size_t) ((1 - ch->num_before) & 3); j < cnt; j += 4) {
@@ -531,31 +559,60 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
     trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
     typedef std::chrono::steady_clock clk;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    uint64_t acc_reads = 0, acc_words = 0;
+    const bool text = !s->cfg.host_pack;  // ship the sequence bytes, the device applies codes[] (pack kernel); else trew_pack_reads here
+    uint64_t acc_reads = 0, acc_words = 0, acc_bytes = 0, acc_bases = 0;
     size_t acc_text = 0;
     bool buffers_free = false;  // has the slot's previous submit been waited for
+    bool same_len = true;       // text batches: every read so far has the length of the first one
     if (w->tmp_off.size() < w->reads_cap) {
         w->tmp_off.resize(w->reads_cap);
         w->tmp_len.resize(w->reads_cap);
+        w->tmp_woff.resize(w->reads_cap);
     }
+    // text batches: the bases start at a fixed place of the pinned buffer, the three index arrays are put right in front of
+    // them when the batch is closed -- [word_offsets][byte_offsets][lengths][bases], which trew_hip_submit_ascii ships in one copy
+    unsigned char *const h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
+    const uint64_t bytes_cap = w->text_cap - 12ull * w->reads_cap;
     auto close_batch = [&]() {
         if (acc_reads == 0) return;
         const clk::time_point t3 = clk::now();
-        uint32_t *h_off = w->h_buf + acc_words, *h_len = h_off + acc_reads;  // [words][offsets][lengths]
-        memcpy(h_off, w->tmp_off.data(), acc_reads * 4);
-        memcpy(h_len, w->tmp_len.data(), acc_reads * 4);
-        submit_packed(s, w, w->h_buf, h_off, h_len, acc_reads, acc_words);
-        acc_reads = acc_words = 0;
+        if (text) {
+            trew_hip_ascii_batch b;
+            memset(&b, 0, sizeof(b));
+            b.bases = (const char *) h_bases;
+            b.n_bytes = acc_bytes;
+            b.n_reads = acc_reads;
+            if (same_len && !job->long_mode) {  // an ordinary Illumina run: no index arrays, and the prefilter takes its uniform-geometry path
+                b.uniform_length = w->tmp_len[0];
+            } else {
+                uint32_t *arr = (uint32_t *) (h_bases - 12ull * acc_reads);
+                memcpy(arr, w->tmp_woff.data(), acc_reads * 4);
+                memcpy(arr + acc_reads, w->tmp_off.data(), acc_reads * 4);
+                memcpy(arr + 2 * acc_reads, w->tmp_len.data(), acc_reads * 4);
+                b.word_offsets = arr;
+                b.byte_offsets = arr + acc_reads;
+                b.lengths = arr + 2 * acc_reads;
+            }
+            submit_text(s, w, b, acc_bases);
+        } else {
+            uint32_t *h_off = w->h_buf + acc_words, *h_len = h_off + acc_reads;  // [words][offsets][lengths]
+            memcpy(h_off, w->tmp_off.data(), acc_reads * 4);
+            memcpy(h_len, w->tmp_len.data(), acc_reads * 4);
+            submit_packed(s, w, w->h_buf, h_off, h_len, acc_reads, acc_words);
+        }
+        acc_reads = acc_words = acc_bytes = acc_bases = 0;
         acc_text = 0;
+        same_len = true;
         buffers_free = false;
         w->t_submit += secs(t3, clk::now());
     };
     for (;;) {
         const clk::time_point t0 = clk::now();
-        if (!job->scan.claim(w->nl, w->st, w->nd)) break;
+        size_t blk = 0;
+        if (!job->scan.claim(w->nl, w->st, w->nd, &blk)) break;
         // the limits of the chunk reader, applied to the same lines
         size_t keep = 0;
-        uint64_t need_words = 0;
+        uint64_t need_words = 0, need_bytes = 0;
         for (size_t i = 0; i < w->st.size(); i++) {
             const int64_t len = w->nd[i] - w->st[i] + 1;
             if (job->long_mode) {
@@ -567,13 +624,14 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
             w->st[keep] = w->st[i];
             w->nd[keep] = w->nd[i];
             need_words += 3ull * (((uint64_t) len + 31) / 32);
+            need_bytes += (uint64_t) (len > 0 ? len : 0);
             keep++;
         }
         const clk::time_point t1 = clk::now();
         w->t_scan += secs(t0, t1);
         // a block holds at most reads_cap sequence lines and words_cap/2 words: it always fits an empty batch
-        if (acc_reads + keep > w->reads_cap || acc_words + need_words > w->words_cap) close_batch();
-        if (keep > w->reads_cap || need_words > w->words_cap) die("internal error: one block's reads do not fit the slot buffer");
+        if (acc_reads + keep > w->reads_cap || acc_words + need_words > w->words_cap || (text && acc_bytes + need_bytes > bytes_cap)) close_batch();
+        if (keep > w->reads_cap || need_words > w->words_cap || (text && need_bytes > bytes_cap)) die("internal error: one block's reads do not fit the slot buffer");
         if (!buffers_free) {
             const clk::time_point tw = clk::now();
             if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
@@ -581,14 +639,37 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
             w->t_wait += secs(tw, clk::now());
         }
         const clk::time_point t2 = clk::now();
-        const uint64_t nw = trew_pack_reads(job->scan.base, w->st.data(), w->nd.data(), keep, w->h_buf + acc_words, w->words_cap - acc_words,
-                                            w->tmp_off.data() + acc_reads, w->tmp_len.data() + acc_reads);
-        if (nw == (uint64_t) -1) die("internal error: packed block exceeds the slot buffer");
-        for (size_t i = 0; i < keep; i++) w->tmp_off[acc_reads + i] += (uint32_t) acc_words;  // offsets count from the batch's first word
-        acc_reads += keep;
-        acc_words += nw;
+        if (text) {
+            // locate + copy: the bytes of the sequence lines back to back; packing is the device's job
+            const char *base = job->scan.base;
+            uint64_t words = acc_words, bytes = acc_bytes;
+            const uint32_t first_len = acc_reads ? w->tmp_len[0] : (keep ? (uint32_t) (w->nd[0] - w->st[0] + 1 > 0 ? w->nd[0] - w->st[0] + 1 : 0) : 0u);
+            for (size_t i = 0; i < keep; i++) {
+                const int64_t n = w->nd[i] - w->st[i] + 1;
+                const uint32_t len = n > 0 ? (uint32_t) n : 0u;
+                memcpy(h_bases + bytes, base + w->st[i], len);
+                w->tmp_woff[acc_reads + i] = (uint32_t) words;
+                w->tmp_off[acc_reads + i] = (uint32_t) bytes;
+                w->tmp_len[acc_reads + i] = len;
+                same_len = same_len && len == first_len;
+                words += 3ull * (((uint64_t) len + 31) / 32);
+                bytes += len;
+            }
+            acc_bases += bytes - acc_bytes;
+            acc_words = words;
+            acc_bytes = bytes;
+            acc_reads += keep;
+        } else {
+            const uint64_t nw = trew_pack_reads(job->scan.base, w->st.data(), w->nd.data(), keep, w->h_buf + acc_words, w->words_cap - acc_words,
+                                                w->tmp_off.data() + acc_reads, w->tmp_len.data() + acc_reads);
+            if (nw == (uint64_t) -1) die("internal error: packed block exceeds the slot buffer");
+            for (size_t i = 0; i < keep; i++) w->tmp_off[acc_reads + i] += (uint32_t) acc_words;  // offsets count from the batch's first word
+            acc_reads += keep;
+            acc_words += nw;
+        }
         acc_text += job->scan.block;
         w->t_pack += secs(t2, clk::now());
+        job->scan.release(blk);  // the block's bytes are in the pinned buffer: drop its page-table entries (see BlockScan::release)
         if (acc_text >= (size_t) s->cfg.batch_mib << 20) close_batch();
     }
     close_batch();
@@ -730,16 +811,36 @@ static bool run_pair_blocks(Scanner *s, const char *name1, const char *name2) {
 // maps the file and runs the block workers; false when the file cannot be mapped (empty file, special file):
 // the caller falls back to the serial reader
 static bool run_blocks(Scanner *s, const char *name, bool long_mode, int slice_length) {
-    Mapping m;
-    if (!m.map(name)) return false;
-    BlockJob job;
-    job.scan.init((const char *) m.p, m.size, (size_t) LENGTH);
-    job.scan.populate = true;
-    job.long_mode = long_mode;
-    job.slice_length = slice_length;
-    std::vector<std::thread> th;
-    for (auto &w : s->workers) th.emplace_back(block_worker_loop, s, &w, &job);
-    for (auto &t : th) t.join();
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
+    {
+        Mapping m;
+        if (!m.map(name)) return false;
+        BlockJob job;
+        // Blocks the workers claim: the reference's chunk size (LENGTH, 4 MiB).  Smaller blocks were measured on the GPU box
+        // (TREW_SCAN_BLOCK_KIB, profiles/r03/README.md) in the hope that the copy of the sequence lines would still find the
+        // block in L2: 2 MiB is 10 % slower, 1 MiB 35 %, 256 KiB five times -- one madvise pair and one hand-over of the line
+        // count per block cost more than the cache misses they save.
+        size_t blk = (size_t) LENGTH;
+        if (const char *e = getenv("TREW_SCAN_BLOCK_KIB")) {
+            const long v = atol(e);
+            if (v >= 64 && v <= 4096) blk = (size_t) v << 10;
+        }
+        job.scan.init((const char *) m.p, m.size, blk);
+        job.scan.populate = true;
+        job.long_mode = long_mode;
+        job.slice_length = slice_length;
+        const clk::time_point t1 = clk::now();
+        std::vector<std::thread> th;
+        for (auto &w : s->workers) th.emplace_back(block_worker_loop, s, &w, &job);
+        for (auto &t : th) t.join();
+        const clk::time_point t2 = clk::now();
+        s->t_map = secs(t0, t1);
+        s->t_workers = secs(t1, t2);
+        s->t_unmap = -secs(t0, t2);  // completed below, once the mapping is gone
+    }
+    s->t_unmap += secs(t0, clk::now());
     return true;
 }
 
@@ -805,7 +906,9 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
         }
         for (auto &t : th) t.join();
     }
+    const auto tc0 = std::chrono::steady_clock::now();
     ResultMapData r = collect_tables(s);
+    s->t_collect = std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
     s->stats = RunStats();
     for (auto &w : s->workers) {
         s->stats.reads += w.reads;
@@ -825,6 +928,7 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
                 "[trew]   per worker (mean seconds): newline scan + line chain %.3f, wait for the slot %.3f, pack %.3f, submit %.3f (of which table "
                 "pressure query %.3f); %llu batches\n",
                 a / n, b / n, c / n, d / n, e / n, (unsigned long long) nsub);
+        fprintf(stderr, "[trew]   wall seconds: map the file %.3f, workers %.3f, unmap %.3f, collect the tables %.3f\n", s->t_map, s->t_workers, s->t_unmap, s->t_collect);
     }
     return process_output(name1, r, cfg.MIN_MER, stdout);  // pair mode prints file 1 only (kmer.cpp:1409)
 }

@@ -38,6 +38,7 @@ struct Config {
     int table_log2_slots = 24;   // device count table: 2^24 slots (256 MiB); emptied into host memory whenever half full
     bool serial_reader = false;  // --serial_reader: plain FASTQ through the reference-shaped single reader as well
     int batch_mib = 32;          // --batch_mib: text per device batch of the block-parallel reader (1..32 MiB)
+    bool host_pack = false;      // --host_pack: the block-parallel reader packs bases on the CPU (trew_pack_reads) instead of shipping text to the pack kernel
 };
 
 // KmerSeq (kmer.h:77) with a total order so that output is deterministic

@@ -27,6 +27,7 @@ struct Slot {
     hipStream_t stream = nullptr;
     u32 *d_buf = nullptr;  // one allocation: [offsets max_batch_reads][lengths max_batch_reads][words max_batch_words + slack]
     u32 *d_words = nullptr, *d_offsets = nullptr, *d_lengths = nullptr;  // views into d_buf
+    unsigned char *d_ascii = nullptr;  // text batches: [word_offsets][byte_offsets][lengths][bases], max_batch_ascii_bytes + slack
     u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
     int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kMaxSlots * kThrRow)
@@ -224,6 +225,10 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             s.d_lengths = s.d_buf + p.max_batch_reads;
             s.d_words = s.d_buf + 2 * (size_t) p.max_batch_reads;
         }
+        if (p.max_batch_ascii_bytes) {
+            if ((e = hipMalloc((void **) &s.d_ascii, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMalloc(text buffer)", e);
+            if ((e = hipMemset(s.d_ascii, 0, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMemset", e);
+        }
         if ((e = hipMalloc((void **) &s.d_thr, kMaxSlots * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
         if ((e = hipHostMalloc((void **) &s.h_thr, kMaxSlots * kThrRow * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
@@ -251,6 +256,7 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     for (auto &s : ctx->slots) {
         if (s.stream) (void) hipStreamSynchronize(s.stream);
         if (s.d_buf) (void) hipFree(s.d_buf);
+        if (s.d_ascii) (void) hipFree(s.d_ascii);
         if (s.d_thr) (void) hipFree(s.d_thr);
         if (s.h_thr) (void) hipHostFree(s.h_thr);
         if (s.d_wl) (void) hipFree(s.d_wl);
@@ -433,15 +439,10 @@ static int stage_thresholds(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, cons
     return 0;
 }
 
-extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot) {
-    if (!ctx || !batch) return -1;
-    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
-    HIPCHK(ctx, hipSetDevice(ctx->p.device));
-    Slot &s = ctx->slots[(size_t) slot];
-    u32 max_seg = 0, max_len = 0;
-    if (int rc = batch_geometry(ctx, batch, &max_seg, &max_len)) return rc;
-    DevBatch db;
-    if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
+static int sync_all(trew_hip_ctx *ctx);
+
+// the two kernels of one staged batch on the slot's stream (everything trew_hip_submit does after the copy)
+static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_seg, u32 max_len) {
     s.n_units = db.n_units;
     if (db.n_units == 0) return 0;
     if (ctx->p.mode == TREW_MODE_SEGMENT) {
@@ -492,6 +493,119 @@ extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, i
 #undef SUBMIT_CHK
     s.n_launches++;
     s.n_submits++;
+    return 0;
+}
+
+extern "C" int trew_hip_submit(trew_hip_ctx *ctx, const trew_hip_batch *batch, int slot) {
+    if (!ctx || !batch) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    Slot &s = ctx->slots[(size_t) slot];
+    u32 max_seg = 0, max_len = 0;
+    if (int rc = batch_geometry(ctx, batch, &max_seg, &max_len)) return rc;
+    DevBatch db;
+    if (int rc = stage_batch(ctx, batch, s, &db)) return rc;
+    return launch_batch(ctx, s, db, max_seg, max_len);
+}
+
+// ---- text batches: copy, pack on the device, then the same two kernels
+static int stage_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *a, Slot &s, DevBatch *db, u64 *n_words_out) {
+    if (!s.d_ascii) return fail(ctx, "the context was created with max_batch_ascii_bytes = 0");
+    if (a->n_reads > ctx->p.max_batch_reads) return fail(ctx, "batch has more reads than max_batch_reads");
+    if (ctx->p.mode == TREW_MODE_PAIR && (a->n_reads & 1)) return fail(ctx, "pair mode needs an even number of reads");
+    const bool ragged = a->word_offsets != nullptr;
+    if (ragged != (a->byte_offsets != nullptr) || ragged != (a->lengths != nullptr)) return fail(ctx, "word_offsets, byte_offsets and lengths must all be given or all be NULL");
+    u64 n_words = 0;
+    if (ragged) {
+        // the pack kernel indexes bases[] and words[] with these: validate on the host, as trew_hip_submit does
+        u64 w = 0;
+        for (u64 i = 0; i < a->n_reads; i++) {
+            if (a->word_offsets[i] != w) return fail(ctx, "word_offsets is not the running sum of the packed read sizes");
+            if ((u64) a->byte_offsets[i] + a->lengths[i] > a->n_bytes) return fail(ctx, "a read's byte offset / length points outside the batch's bases");
+            w += 3ull * (((u64) a->lengths[i] + 31ull) / 32ull);
+            if (w > 0xffffffffull) return fail(ctx, "batch packs to more than 2^32 words");
+        }
+        n_words = w;
+        if (a->n_bytes + 12ull * a->n_reads > ctx->p.max_batch_ascii_bytes) return fail(ctx, "text batch larger than max_batch_ascii_bytes");
+    } else {
+        if (a->uniform_length == 0 && a->n_reads) return fail(ctx, "uniform text batch without uniform_length");
+        if (a->n_reads * (u64) a->uniform_length > a->n_bytes) return fail(ctx, "uniform text batch: n_reads * uniform_length exceeds n_bytes");
+        if (a->n_bytes > ctx->p.max_batch_ascii_bytes) return fail(ctx, "text batch larger than max_batch_ascii_bytes");
+        n_words = a->n_reads * 3ull * (((u64) a->uniform_length + 31ull) / 32ull);
+    }
+    if (n_words > ctx->p.max_batch_words) return fail(ctx, "batch has more words than max_batch_words");
+    *n_words_out = n_words;
+    db->n_reads = a->n_reads;
+    db->n_units = ctx->p.mode == TREW_MODE_PAIR ? a->n_reads / 2 : a->n_reads;
+    db->words = s.d_words;
+    if (a->n_reads == 0) return 0;
+    const unsigned char *d_bases;
+    const u32 *d_wo = nullptr, *d_bo = nullptr, *d_len = nullptr;
+    if (ragged) {
+        u32 *arr = (u32 *) s.d_ascii;
+        d_wo = arr;
+        d_bo = arr + a->n_reads;
+        d_len = arr + 2 * a->n_reads;
+        d_bases = s.d_ascii + 12ull * a->n_reads;
+        const bool one = a->byte_offsets == a->word_offsets + a->n_reads && a->lengths == a->byte_offsets + a->n_reads &&
+                         (const void *) a->bases == (const void *) (a->lengths + a->n_reads);
+        if (one) {  // [word_offsets][byte_offsets][lengths][bases] in one pinned buffer: ONE copy
+            HIPCHK(ctx, hipMemcpyAsync(s.d_ascii, a->word_offsets, 12ull * a->n_reads + a->n_bytes, hipMemcpyHostToDevice, s.stream));
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(arr, a->word_offsets, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(ctx, hipMemcpyAsync(arr + a->n_reads, a->byte_offsets, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(ctx, hipMemcpyAsync(arr + 2 * a->n_reads, a->lengths, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
+            HIPCHK(ctx, hipMemcpyAsync(s.d_ascii + 12ull * a->n_reads, a->bases, a->n_bytes, hipMemcpyHostToDevice, s.stream));
+        }
+        db->offsets = d_wo;
+        db->lengths = d_len;
+        db->uniform_length = 0;
+        db->uniform_stride = 0;
+    } else {
+        d_bases = s.d_ascii;
+        HIPCHK(ctx, hipMemcpyAsync(s.d_ascii, a->bases, a->n_reads * (u64) a->uniform_length, hipMemcpyHostToDevice, s.stream));
+        db->offsets = nullptr;
+        db->lengths = nullptr;
+        db->uniform_length = a->uniform_length;
+        db->uniform_stride = 3u * ((a->uniform_length + 31u) / 32u);
+    }
+    HIPCHK(ctx, launch_pack_ascii(s.stream, d_bases, d_bo, d_len, d_wo, a->uniform_length, a->n_reads, n_words / 3ull, s.d_words));
+    return 0;
+}
+
+static int ascii_geometry(trew_hip_ctx *ctx, const trew_hip_ascii_batch *a, u32 *max_seg, u32 *max_len) {
+    trew_hip_batch view;
+    memset(&view, 0, sizeof(view));
+    view.lengths = a->lengths;
+    view.offsets = a->word_offsets;
+    view.uniform_length = a->uniform_length;
+    view.n_reads = a->n_reads;
+    return batch_geometry(ctx, &view, max_seg, max_len);
+}
+
+extern "C" int trew_hip_submit_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *batch, int slot) {
+    if (!ctx || !batch) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    Slot &s = ctx->slots[(size_t) slot];
+    u32 max_seg = 0, max_len = 0;
+    if (int rc = ascii_geometry(ctx, batch, &max_seg, &max_len)) return rc;
+    DevBatch db;
+    u64 n_words = 0;
+    if (int rc = stage_ascii(ctx, batch, s, &db, &n_words)) return rc;
+    return launch_batch(ctx, s, db, max_seg, max_len);
+}
+
+extern "C" int trew_hip_pack_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *batch, uint32_t *words, uint64_t words_cap, uint64_t *n_words) {
+    if (!ctx || !batch || !n_words) return -1;
+    if (int rc = sync_all(ctx)) return rc;
+    Slot &s = ctx->slots[0];
+    u32 max_seg = 0, max_len = 0;
+    if (int rc = ascii_geometry(ctx, batch, &max_seg, &max_len)) return rc;
+    DevBatch db;
+    if (int rc = stage_ascii(ctx, batch, s, &db, n_words)) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    if (words && *n_words && *n_words <= words_cap) HIPCHK(ctx, hipMemcpy(words, s.d_words, *n_words * 4, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -212,6 +212,14 @@ hipError_t launch_add_gathered(hipStream_t st, const DevTable &T, const trew_hip
     return hipGetLastError();
 }
 
+hipError_t launch_pack_ascii(hipStream_t st, const unsigned char *d_bases, const u32 *d_byte_offsets, const u32 *d_lengths, const u32 *d_word_offsets,
+                             u32 uniform_length, u64 n_reads, u64 n_triples, u32 *d_words) {
+    if (n_triples == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_ascii_kernel, dim3((u32) ((n_triples + 255) / 256)), dim3(256), 0, st, d_bases, d_byte_offsets, d_lengths, d_word_offsets, uniform_length,
+                       n_reads, n_triples, d_words);
+    return hipGetLastError();
+}
+
 hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n) {
     const u64 total = n_slots + (1ull << wide_log2_slots);

@@ -19,6 +19,8 @@ hipError_t fallback_counters_read(u32 *out);  // kFallbackWords words of the cur
 hipError_t fallback_counters_clear();
 hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n, u32 *d_flags);
 hipError_t launch_add_gathered(hipStream_t st, const DevTable &T, const trew_hip_row *d_buf, u32 n_slices, u32 own, u64 slice_rows, u32 *d_flags);
+hipError_t launch_pack_ascii(hipStream_t st, const unsigned char *d_bases, const u32 *d_byte_offsets, const u32 *d_lengths, const u32 *d_word_offsets,
+                             u32 uniform_length, u64 n_reads, u64 n_triples, u32 *d_words);
 hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n);
 hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
