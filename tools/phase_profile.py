@@ -11,7 +11,12 @@ from trew_amd import capi
 mode = sys.argv[1] if len(sys.argv) > 1 else "short"
 lib = capi.load()
 n, L = 10_000_000, 150
-if mode == "pair":
+to_free = []
+if mode == "long":
+    n = 1_000_000
+    t = T.TrewHip(mode=T.MODE_LONG, n_slots=1, max_batch_words=16, max_batch_reads=n, table_log2_slots=20)
+    b, to_free, _ = t.synth_long_device(20250218, 0, n)
+elif mode == "pair":
     t = T.TrewHip(mode=T.MODE_PAIR, n_slots=1, max_batch_words=16, max_batch_reads=2 * n, table_log2_slots=20)
     d = t.malloc(2 * n * 60 + 64)
     t.synth_pair_device(20250218, 0, n, L, d)

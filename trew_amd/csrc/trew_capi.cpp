@@ -714,7 +714,11 @@ extern "C" int trew_hip_collect(trew_hip_ctx *ctx, int table, trew_hip_row *rows
                 else
                     rows[m++] = rows[i];
             }
-            n = m;
+            // a key whose counts were moved elsewhere (run_long subtracts what it re-files) may sum to zero: not a row
+            u64 z = 0;
+            for (u64 i = 0; i < m; i++)
+                if (rows[i].count) rows[z++] = rows[i];
+            n = z;
         }
     }
     *n_rows = n;

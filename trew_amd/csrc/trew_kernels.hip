@@ -141,7 +141,10 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     const u32 lds = exact_lds_bytes(cap, rawwords, wide ? 16u : 8u);
     // max_seg_len = longest segment decide() is ever called on (halves, whole-read check, slices)
     // (k = 64 itself has no lane bound -- decide() walks its windows -- but every smaller k of a MAX_MER = 64 run does)
-    const int nw = (P.flags & TREW_FLAG_NO_FILTER) ? 0 : (max_seg_len <= 95 ? 3 : max_seg_len <= 159 ? 5 : max_seg_len <= 319 ? 10 : 0);
+    // long mode: the kernel is built for the regular slice (SLICE_LENGTH bases); its driver decides the one longer middle slice
+    // without lane bounds (run_long), so that slice does not set the register budget
+    const u32 bound_len = P.mode == TREW_MODE_LONG ? (u32) P.slice_len : max_seg_len;
+    const int nw = (P.flags & TREW_FLAG_NO_FILTER) ? 0 : (bound_len <= 95 ? 3 : bound_len <= 159 ? 5 : bound_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
     typedef void (*kern_t)(DevParams, DevBatch, DevTable, const u32 *, u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
