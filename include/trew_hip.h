@@ -57,8 +57,12 @@ enum {
     TREW_FLAG_DEBUG_POISON_LDS = 32, /* tests: the exact kernel starts from garbage-filled LDS */
     TREW_FLAG_DEBUG_WIDE_NO_WAIT = 128, /* tests: the wide table (k > 32) never waits for a claimed slot's ready bit -- every such
                                   wait counts as timed out (trew_hip_debug_counters), duplicates are left for collect to merge */
-    TREW_FLAG_NO_TIMING = 64 /* no HIP events around the kernels (trew_hip_last_timing is unavailable): for hosts that
+    TREW_FLAG_NO_TIMING = 64, /* no HIP events around the kernels (trew_hip_last_timing is unavailable): for hosts that
                                 submit ~10^4 small batches a second and are bound by API calls */
+    TREW_FLAG_TRACK_PRESSURE = 256 /* every batch ends with a copy of the table's fill counters into pinned host memory, and
+                                trew_hip_table_pressure answers from those copies (and from what collect / add_rows /
+                                reset read since) instead of asking the device: for hosts that ask before every batch.
+                                Like the device query, the answer does not include batches still in flight. */
 };
 
 /* Replaces the eight configuration globals MIN_MER ... HIGH_BASELINE
@@ -71,7 +75,7 @@ typedef struct {
     int32_t slice_length;     /* SLICE_LENGTH (-s), long mode only                            */
     int32_t mode;             /* TREW_MODE_*                                                  */
     int32_t device;           /* HIP device ordinal                                           */
-    int32_t n_slots;          /* batch slots (one HIP stream each), >= 1                      */
+    int32_t n_slots;          /* batch slots (one HIP stream each), 1 .. 512                  */
     uint64_t max_batch_words; /* capacity of one slot's packed-read buffer, 32-bit words      */
     uint64_t max_batch_reads; /* capacity of one slot, reads (pairs count as two)             */
     uint32_t table_log2_slots;/* device count table: 2^table_log2_slots entries (>= 12)       */
@@ -194,7 +198,7 @@ int trew_hip_add_gathered_device(trew_hip_ctx *ctx, const trew_hip_row *d_buf, u
  * find their partition full go to a spill log of spill_capacity rows, and only a full log loses counts (then
  * trew_hip_collect fails).  A host that scans unbounded input calls this between batches and, when
  * used_slots nears total_slots or spilled_rows > 0, drains: trew_hip_collect, keep the rows, trew_hip_reset_tables.
- * Any pointer may be NULL. */
+ * Any pointer may be NULL.  With TREW_FLAG_TRACK_PRESSURE the call touches no device (see the flag). */
 int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *total_slots, uint64_t *spilled_rows,
                             uint64_t *spill_capacity);
 

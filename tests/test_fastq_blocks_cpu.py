@@ -30,8 +30,9 @@ def reference_rule(data: bytes):
     return out
 
 
-def run(exe, path, block, threads):
-    r = subprocess.run([exe, path, str(block), str(threads)], capture_output=True, text=True, check=True)
+def run(exe, path, block, threads, isa=None):
+    env = dict(os.environ, TREW_SCAN_ISA=isa) if isa else None
+    r = subprocess.run([exe, path, str(block), str(threads)], capture_output=True, text=True, check=True, env=env)
     return [tuple(int(x) for x in line.split()) for line in r.stdout.splitlines()]
 
 
@@ -66,6 +67,9 @@ def test_blocks_find_the_reference_lines(harness, tmp_path, name):
         if block < 7 and len(data) > 20000:
             continue  # a block per byte is pointless on the big cases
         assert run(harness, path, block, threads) == want, (name, block, threads)
+    # the newline scan has an AVX2 form (the default, above), an opt-in AVX-512 form and a memchr form
+    for isa in ("avx512", "scalar"):
+        assert run(harness, path, 4096, 2, isa) == want, (name, isa)
 
 
 def test_paired_reader_helpers(harness, tmp_path):

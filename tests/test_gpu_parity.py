@@ -1,5 +1,6 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI.  GPU only."""
 import os
+import random
 
 import numpy as np
 import pytest
@@ -953,6 +954,50 @@ def test_results_do_not_depend_on_lds_residue():
         t.submit_reads(lr)
         t.wait()
         assert t.collect() == O.run_long(O.OracleParams(slice_len=150), lr)
+
+
+def test_tracked_pressure_needs_no_device_query():
+    """TREW_FLAG_TRACK_PRESSURE (what the `trew` host runs with): the fill counters travel back with every batch, and
+    trew_hip_table_pressure reads those copies -- same numbers as the device query of a context without the flag once the
+    batches are waited for, over both slots, across a reset and after rows were added from outside; a tiny table reports
+    its spilled rows the same way."""
+    buf, st, nd = capi.synth_short_ascii(20250218, 3, 20000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    reads += [r for rep in range(4) for r in edge_reads(30 + rep) if len(r) <= 1000]  # many distinct keys: a 4096-slot table spills
+    random.Random(5).shuffle(reads)
+    third = len(reads) // 3
+
+    def same(a, b):
+        # which of two racing rows of a full partition goes to the spill log is a matter of timing: with the tiny table only
+        # the row counts of the tables themselves are comparable, and that both contexts report spilled rows
+        pa, pb = a.table_pressure(), b.table_pressure()
+        assert pa == pb or (pa[1] == 4096 and pa[0] == pb[0] and pa[2] > 0 and pb[2] > 0 and pa[3] == pb[3]), (pa, pb)
+
+    for log2 in (20, 12):
+        with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=third + 8, flags=T.FLAG_TRACK_PRESSURE, table_log2_slots=log2) as a, \
+                T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=third + 8, table_log2_slots=log2) as b:
+            assert a.table_pressure()[0] == 0
+            for t in (a, b):
+                t.submit_reads(reads[:third], slot=0)
+                t.submit_reads(reads[third:2 * third], slot=1)
+                t.wait(0)
+                t.wait(1)
+            same(a, b)
+            assert a.table_pressure()[0] > 0 and (log2 == 20 or a.table_pressure()[2] > 0)
+            rows = b.collect()
+            a.reset_tables()
+            b.reset_tables()
+            assert a.table_pressure()[0] == 0 and a.table_pressure()[2] == 0
+            for t in (a, b):
+                t.submit_reads(reads[2 * third:], slot=1)
+                t.wait(1)
+            same(a, b)
+            before = a.table_pressure()[0]
+            a.add_rows(capi.tables_to_rows(rows))
+            b.add_rows(capi.tables_to_rows(rows))
+            same(a, b)
+            assert a.table_pressure()[0] >= before
+            assert a.collect() == b.collect()
 
 
 def test_table_reduction_entry_points():

@@ -162,6 +162,10 @@ private:
 struct Worker {
     int dev_index = 0;  // index into Scanner::dev
     int slot = 0;
+    // the block-parallel reader alternates between two slots (and two pinned buffers): it fills one batch while the previous
+    // one is still on its way to the device, instead of waiting for the copy (13 % of a worker's time with one, --stats)
+    int slot_b = 0;
+    uint32_t *h_buf_b = nullptr;
     // one pinned allocation; a batch is laid out [offsets n][lengths n][words] (serial reader: n is known before
     // packing) or [words][offsets n][lengths n] (block reader: reads accumulate), either of which trew_hip_submit
     // ships with a single copy (include/trew_hip.h, trew_hip_batch)
@@ -227,12 +231,14 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         p.slice_length = cfg.SLICE_LENGTH;
         p.mode = mode;
         p.device = cfg.devices[(size_t) d];
-        p.n_slots = std::max(1, slots_on_dev[(size_t) d]);
+        p.n_slots = 2 * std::max(1, slots_on_dev[(size_t) d]);
         p.max_batch_words = words_cap;
         p.max_batch_reads = reads_cap;
         p.table_log2_slots = (uint32_t) cfg.table_log2_slots;
         p.max_batch_ascii_bytes = cfg.host_pack ? 0 : text_cap;
-        p.flags = TREW_FLAG_NO_TIMING;  // ~10^4 small batches a second: every HIP call per batch counts
+        // ~10^4 small batches a second: every HIP call per batch counts -- no timing events, and the table's fill state comes
+        // back with every batch instead of being asked for before every batch (0.4 ms a query with 15 threads asking)
+        p.flags = TREW_FLAG_NO_TIMING | TREW_FLAG_TRACK_PRESSURE;
         trew_hip_ctx *c = nullptr;
         if (trew_hip_init(&p, &c) != 0) die(trew_hip_last_error(nullptr));
         s->dev.emplace_back(new Device());
@@ -243,11 +249,13 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         Worker wk;
         wk.dev_index = w % ndev;
         wk.slot = next_slot[(size_t) wk.dev_index]++;
+        wk.slot_b = next_slot[(size_t) wk.dev_index]++;
         wk.words_cap = words_cap;
         wk.reads_cap = reads_cap;
         trew_hip_ctx *c = s->dev[(size_t) wk.dev_index]->ctx;
         wk.text_cap = text_cap;
         if (trew_hip_host_alloc(c, std::max<uint64_t>((words_cap + 2 * reads_cap) * 4, text_cap + 64), (void **) &wk.h_buf)) hip_die(c, "pinned allocation");
+        if (trew_hip_host_alloc(c, std::max<uint64_t>((words_cap + 2 * reads_cap) * 4, text_cap + 64), (void **) &wk.h_buf_b)) hip_die(c, "pinned allocation");
         s->workers.push_back(std::move(wk));
     }
     return s;
@@ -258,6 +266,7 @@ void scanner_destroy(Scanner *s) {
     for (auto &w : s->workers) {
         trew_hip_ctx *c = s->dev[(size_t) w.dev_index]->ctx;
         trew_hip_host_free(c, w.h_buf);
+        trew_hip_host_free(c, w.h_buf_b);
     }
     for (auto &d : s->dev) trew_hip_destroy(d->ctx);
     delete s;
@@ -555,11 +564,24 @@ struct BlockJob {
     int slice_length = 0;
 };
 
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static inline void copy_short_line(unsigned char *dst, const char *src, uint32_t len) {
+    for (uint32_t o = 0; o < len; o += 32) _mm256_storeu_si256((__m256i *) (dst + o), _mm256_loadu_si256((const __m256i *) (src + o)));
+}
+#else
+static inline void copy_short_line(unsigned char *dst, const char *src, uint32_t len) { memcpy(dst, src, len); }
+#endif
+
 static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
     trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
     typedef std::chrono::steady_clock clk;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const bool text = !s->cfg.host_pack;  // ship the sequence bytes, the device applies codes[] (pack kernel); else trew_pack_reads here
+#if defined(__x86_64__)
+    const bool inline_copy = __builtin_cpu_supports("avx2") && !getenv("TREW_AB_MEMCPY");
+#else
+    const bool inline_copy = false;
+#endif
     uint64_t acc_reads = 0, acc_words = 0, acc_bytes = 0, acc_bases = 0;
     size_t acc_text = 0;
     bool buffers_free = false;  // has the slot's previous submit been waited for
@@ -571,7 +593,7 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
     }
     // text batches: the bases start at a fixed place of the pinned buffer, the three index arrays are put right in front of
     // them when the batch is closed -- [word_offsets][byte_offsets][lengths][bases], which trew_hip_submit_ascii ships in one copy
-    unsigned char *const h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
+    unsigned char *h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
     const uint64_t bytes_cap = w->text_cap - 12ull * w->reads_cap;
     auto close_batch = [&]() {
         if (acc_reads == 0) return;
@@ -603,6 +625,11 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
         acc_reads = acc_words = acc_bytes = acc_bases = 0;
         acc_text = 0;
         same_len = true;
+        // the next batch goes to the other slot and the other pinned buffer (that slot's previous batch was submitted one
+        // batch ago: the wait below rarely blocks)
+        std::swap(w->slot, w->slot_b);
+        std::swap(w->h_buf, w->h_buf_b);
+        h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
         buffers_free = false;
         w->t_submit += secs(t3, clk::now());
     };
@@ -644,10 +671,17 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
             const char *base = job->scan.base;
             uint64_t words = acc_words, bytes = acc_bytes;
             const uint32_t first_len = acc_reads ? w->tmp_len[0] : (keep ? (uint32_t) (w->nd[0] - w->st[0] + 1 > 0 ? w->nd[0] - w->st[0] + 1 : 0) : 0u);
+            // short lines are copied 32 bytes at a time past their end (the next line overwrites the excess, the pinned buffer
+            // has 64 bytes of slack, and the source stays inside the mapping): a libc memcpy call per 150-byte line costs as
+            // much as finding the line (profiles/r03/README.md, end to end)
+            const int64_t safe_src = (int64_t) job->scan.size - 288;
             for (size_t i = 0; i < keep; i++) {
                 const int64_t n = w->nd[i] - w->st[i] + 1;
                 const uint32_t len = n > 0 ? (uint32_t) n : 0u;
-                memcpy(h_bases + bytes, base + w->st[i], len);
+                if (inline_copy && len <= 256 && w->st[i] <= safe_src)
+                    copy_short_line(h_bases + bytes, base + w->st[i], len);
+                else
+                    memcpy(h_bases + bytes, base + w->st[i], len);
                 w->tmp_woff[acc_reads + i] = (uint32_t) words;
                 w->tmp_off[acc_reads + i] = (uint32_t) bytes;
                 w->tmp_len[acc_reads + i] = len;
@@ -673,7 +707,7 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
         if (acc_text >= (size_t) s->cfg.batch_mib << 20) close_batch();
     }
     close_batch();
-    if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");
+    if (trew_hip_wait(c, w->slot) || trew_hip_wait(c, w->slot_b)) hip_die(c, "trew_hip_wait");
 }
 
 // ------------------------------------------------------------------ block-parallel reader, paired files
@@ -751,9 +785,11 @@ static void pair_worker_loop(Scanner *s, Worker *w, PairJob *job) {
             w->t_pack += secs(t2, t3);
             w->t_submit += secs(t3, clk::now());
             at += n;
+            std::swap(w->slot, w->slot_b);  // two slots, two pinned buffers: pack the next batch while this one travels
+            std::swap(w->h_buf, w->h_buf_b);
         }
     }
-    if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");
+    if (trew_hip_wait(c, w->slot) || trew_hip_wait(c, w->slot_b)) hip_die(c, "trew_hip_wait");
 }
 
 struct Mapping {

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,7 @@ struct Slot {
     u32 *d_wl_count = nullptr;
     int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kMaxSlots * kThrRow)
     int2 *h_thr = nullptr;   // pinned staging of the same
+    u32 *h_seen = nullptr;   // TREW_FLAG_TRACK_PRESSURE: the counter line as of the end of this slot's last batch (pinned, behind h_thr)
     u32 thr_length = 0;      // uniform read length d_thr was computed for (0: none yet)
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
     // ring of (before filter, between, after exact) events: submits may be queued back to back
@@ -75,7 +77,20 @@ struct trew_hip_ctx {
     u32 *d_row_flags = nullptr;  // kRowFlagWords words: verdict of the validation pass of the row-adding entry points
     hipEvent_t ev_producer = nullptr;  // orders slot 0's stream behind a caller's stream (trew_hip_add_gathered_device)
     std::mutex table_mu;  // collect / reset / add_rows / merge are whole-table operations: one at a time
+    // TREW_FLAG_TRACK_PRESSURE: the largest value of each fill counter any host thread has read so far (they only grow
+    // between resets); trew_hip_table_pressure answers from these
+    std::atomic<u32> seen[kDiagWords];
+    std::mutex seen_mu;  // keeps a reset (which zeroes the copies) apart from a query that folds them
 };
+
+// fold one copy of the counter line into ctx->seen
+static void note_seen(trew_hip_ctx *ctx, const u32 *diag) {
+    for (int i : {(int) kDiagOverflow, (int) kDiagInserted, (int) kDiagInsertedWide, (int) kDiagSpillRows}) {
+        u32 cur = ctx->seen[i].load(std::memory_order_relaxed);
+        while (cur < diag[i] && !ctx->seen[i].compare_exchange_weak(cur, diag[i], std::memory_order_relaxed)) {
+        }
+    }
+}
 
 #define HIPCHK(ctx, expr)                                                                         \
     do {                                                                                          \
@@ -148,7 +163,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         if (p.slice_length < 2 * p.max_mer) { g_init_error = "SLICE_LENGTH must be greater than or equal to twice of MAX_MER."; return -1; }
         if (2 * p.slice_length - 1 > kMaxSegBases) { g_init_error = "SLICE_LENGTH must be at most 512 on the HIP path."; return -1; }
     }
-    if (p.n_slots < 1 || p.n_slots > 16) { g_init_error = "n_slots must be in [1,16]"; return -1; }
+    if (p.n_slots < 1 || p.n_slots > 512) { g_init_error = "n_slots must be in [1,512]"; return -1; }
     if (p.table_log2_slots < 12 || p.table_log2_slots > 30) { g_init_error = "table_log2_slots must be in [12,30]"; return -1; }
     if (p.max_batch_reads == 0 || p.max_batch_reads > 0xfffffff0ull) { g_init_error = "max_batch_reads out of range"; return -1; }
 
@@ -163,6 +178,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
     if (e != hipSuccess) { g_init_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return -2; }
 
     trew_hip_ctx *ctx = new trew_hip_ctx();
+    for (auto &v : ctx->seen) v.store(0, std::memory_order_relaxed);
     memset(&ctx->table, 0, sizeof(ctx->table));
     memset(&ctx->wide, 0, sizeof(ctx->wide));
     ctx->p = p;
@@ -203,8 +219,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         ctx->wide.spill_cap = (u32) std::max<u64>(1ull << 16, ctx->table_slots >> 4);
         ctx->wide.spin_limit = (p.flags & TREW_FLAG_DEBUG_WIDE_NO_WAIT) ? 0u : (1u << 20);
         if ((e = hipMalloc((void **) &ctx->wide.spill_rows, (size_t) ctx->wide.spill_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(spill log)", e);
-        if ((e = hipMalloc((void **) &ctx->wide.spill_n, 4)) != hipSuccess) return bail("hipMalloc(spill counter)", e);
-        if ((e = hipMemset(ctx->wide.spill_n, 0, 4)) != hipSuccess) return bail("hipMemset", e);
+        ctx->wide.spill_n = ctx->table.overflow + kDiagSpillRows;  // cleared with the counter line
         DevWide *dw = nullptr;
         if ((e = hipMalloc((void **) &dw, sizeof(DevWide))) != hipSuccess) return bail("hipMalloc(wide descriptor)", e);
         if ((e = hipMemcpy(dw, &ctx->wide, sizeof(DevWide), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
@@ -230,7 +245,9 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMemset(s.d_ascii, 0, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMemset", e);
         }
         if ((e = hipMalloc((void **) &s.d_thr, kMaxSlots * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
-        if ((e = hipHostMalloc((void **) &s.h_thr, kMaxSlots * kThrRow * sizeof(int2), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
+        if ((e = hipHostMalloc((void **) &s.h_thr, kMaxSlots * kThrRow * sizeof(int2) + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
+        s.h_seen = (u32 *) (s.h_thr + kMaxSlots * kThrRow);
+        memset(s.h_seen, 0, kDiagWords * 4);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
         if ((e = hipMemset(s.d_wl_count, 0, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMemset", e);
@@ -280,7 +297,6 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->wide.whi) (void) hipFree(ctx->wide.whi);
     if (ctx->wide.wcount) (void) hipFree(ctx->wide.wcount);
     if (ctx->wide.spill_rows) (void) hipFree(ctx->wide.spill_rows);
-    if (ctx->wide.spill_n) (void) hipFree(ctx->wide.spill_n);
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
@@ -493,6 +509,8 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
 #undef SUBMIT_CHK
     s.n_launches++;
     s.n_submits++;
+    if (ctx->p.flags & TREW_FLAG_TRACK_PRESSURE)  // 64 bytes into pinned memory; trew_hip_table_pressure reads them there
+        HIPCHK(ctx, hipMemcpyAsync(s.h_seen, ctx->table.overflow, kDiagWords * 4, hipMemcpyDeviceToHost, s.stream));
     return 0;
 }
 
@@ -626,6 +644,7 @@ static int sync_all(trew_hip_ctx *ctx) {
 // reads the device counters; a non-zero "cannot happen" counter is an error, never a silent loss
 static int check_diag(trew_hip_ctx *ctx, u32 (&diag)[kDiagWords]) {
     HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
+    note_seen(ctx, diag);
     if (diag[kDiagOverflow]) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
     if (diag[kDiagWorklistDrop]) return fail(ctx, "internal error: the prefilter worklist overflowed (survivors were dropped)");
     if (diag[kDiagIntentDrop]) return fail(ctx, "internal error: a pair logged more than 32 deferred emissions (some were dropped)");
@@ -742,8 +761,11 @@ static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->wide.wlo, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
-    HIPCHK(ctx, hipMemset(ctx->wide.spill_n, 0, 4));
     HIPCHK(ctx, fallback_counters_clear());
+    // the callers have synchronised every slot: no copy into h_seen is in flight
+    std::lock_guard<std::mutex> lk(ctx->seen_mu);
+    for (auto &sl : ctx->slots) memset(sl.h_seen, 0, kDiagWords * 4);
+    for (auto &v : ctx->seen) v.store(0, std::memory_order_relaxed);
     return 0;
 }
 
@@ -759,10 +781,21 @@ extern "C" int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, 
     if (!ctx) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->p.device));
     u32 diag[kDiagWords];
-    u32 n_spill = 0;
-    // plain blocking copies: a snapshot of monotonic counters, the slot streams are not waited for
-    HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
-    HIPCHK(ctx, hipMemcpy(&n_spill, ctx->wide.spill_n, 4, hipMemcpyDeviceToHost));
+    if (ctx->p.flags & TREW_FLAG_TRACK_PRESSURE) {
+        // every slot's copy, finished or still being written: the counters only grow between resets and a copy lands a
+        // whole word at a time, so any mix of old and new words is a valid (slightly old) reading
+        std::lock_guard<std::mutex> lk(ctx->seen_mu);
+        for (auto &sl : ctx->slots) {
+            u32 copy[kDiagWords];
+            for (int i = 0; i < kDiagWords; i++) copy[i] = ((volatile const u32 *) sl.h_seen)[i];
+            note_seen(ctx, copy);
+        }
+        for (int i = 0; i < kDiagWords; i++) diag[i] = ctx->seen[i].load(std::memory_order_relaxed);
+    } else {
+        // a plain blocking copy: a snapshot of monotonic counters, the slot streams are not waited for
+        HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
+    }
+    const u32 n_spill = diag[kDiagSpillRows];
     // the narrow and the wide table fill independently: report the fuller one, scaled to the narrow table's size
     const u64 wide_slots = 1ull << ctx->wide.wide_log2_slots;
     const u64 wide_scaled = (u64) ((double) diag[kDiagInsertedWide] / (double) wide_slots * (double) ctx->table_slots);

@@ -52,6 +52,7 @@ enum {
     kDiagInserted = 3,     // keys inserted into the narrow table (occupancy, trew_hip_table_pressure)
     kDiagInsertedWide = 4, // keys inserted into the wide table
     kDiagBadRow = 5,       // unused since ABI 3 (rows are validated in a pass of their own, see kRowFlag*)
+    kDiagSpillRows = 6,    // rows in the spill log (DevWide::spill_n points here: one copy reads the whole fill state)
     kDiagWords = 16
 };
 
