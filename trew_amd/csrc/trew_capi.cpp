@@ -33,6 +33,7 @@ struct Slot {
     u32 *d_wl_count = nullptr;
     int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kMaxSlots * kThrRow)
     int2 *h_thr = nullptr;   // pinned staging of the same
+    hipEvent_t ev_tail = nullptr, ev_copied = nullptr;  // order the context's copy stream behind / in front of this slot's stream (BatchCopy)
     u32 *h_seen = nullptr;   // TREW_FLAG_TRACK_PRESSURE: the counter line as of the end of this slot's last batch (pinned, behind h_thr)
     u32 thr_length = 0;      // uniform read length d_thr was computed for (0: none yet)
     SegResults res = {nullptr, nullptr, nullptr, nullptr};
@@ -63,9 +64,16 @@ struct trew_hip_ctx {
     trew_hip_params p;
     DevParams dp;
     DevTable table;
+    DevTable *d_table = nullptr;  // device copy of `table` for the exact kernels, which take it by pointer (exact_core.inc, TableRef)
     DevWide wide;  // host copy of *table.wide
     u64 table_slots = 0;
     std::vector<Slot> slots;
+    // Every host-to-device copy of a batch goes through this ONE stream, whatever slot it is for.  On ROCm 7 the first DMA-engine
+    // copy that a stream issues costs 3.5 ms of host time under a process-wide lock (measured: 30 slots = 0.105 s of a 0.22 s
+    // file, the workers of the `trew` host queueing up behind each other, profiles/r03/README.md); after that a 16 MB copy is
+    // queued in microseconds.  The link carries one copy at a time anyway, so one stream loses no bandwidth.
+    hipStream_t copy_stream = nullptr;
+    std::mutex copy_mu;  // a batch's copies and the event behind them are queued as one unit
     int n_cu = 256;
     // persistent scratch of trew_hip_collect (device-side compaction)
     unsigned long long *d_collect_n = nullptr;
@@ -225,12 +233,21 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         if ((e = hipMemcpy(dw, &ctx->wide, sizeof(DevWide), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
         ctx->table.wide = dw;
     }
+    {
+        DevTable tbl = ctx->table;
+        if (p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;  // cached_add drops every row
+        if ((e = hipMalloc((void **) &ctx->d_table, sizeof(DevTable))) != hipSuccess) return bail("hipMalloc(table descriptor)", e);
+        if ((e = hipMemcpy(ctx->d_table, &tbl, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    }
 
     if ((e = hipMalloc((void **) &ctx->d_row_flags, kRowFlagWords * 4)) != hipSuccess) return bail("hipMalloc(row flags)", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_producer, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->slots.resize((size_t) p.n_slots);
     for (auto &s : ctx->slots) {
         if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&s.ev_copied, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         {
             // +8 words of slack: the exact kernel fetches whole 64-word heads of a read
             const size_t words = 2 * (size_t) p.max_batch_reads + (size_t) p.max_batch_words + 8;
@@ -287,8 +304,11 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
         for (int i = 0; i < Slot::kRing; i++)
             for (int j = 0; j < 3; j++)
                 if (s.ev[i][j]) (void) hipEventDestroy(s.ev[i][j]);
+        if (s.ev_tail) (void) hipEventDestroy(s.ev_tail);
+        if (s.ev_copied) (void) hipEventDestroy(s.ev_copied);
         if (s.stream) (void) hipStreamDestroy(s.stream);
     }
+    if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
     if (ctx->table.keys) (void) hipFree(ctx->table.keys);
     if (ctx->table.counts) (void) hipFree(ctx->table.counts);
     if (ctx->table.overflow) (void) hipFree(ctx->table.overflow);
@@ -298,6 +318,7 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->wide.wcount) (void) hipFree(ctx->wide.wcount);
     if (ctx->wide.spill_rows) (void) hipFree(ctx->wide.spill_rows);
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
+    if (ctx->d_table) (void) hipFree(ctx->d_table);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
     if (ctx->d_add_rows) (void) hipFree(ctx->d_add_rows);
@@ -379,6 +400,34 @@ static int batch_geometry(trew_hip_ctx *ctx, const trew_hip_batch *b, u32 *max_s
     return 0;
 }
 
+// The host-to-device copies of one batch: queued on the context's copy stream (see trew_hip_ctx::copy_stream), behind whatever
+// the slot's stream still has to do with the slot's device buffers and in front of the kernels that follow on it.
+struct BatchCopy {
+    trew_hip_ctx *ctx;
+    Slot &s;
+    std::unique_lock<std::mutex> lk;
+    BatchCopy(trew_hip_ctx *c, Slot &sl) : ctx(c), s(sl) {}
+    int begin() {
+        lk = std::unique_lock<std::mutex>(ctx->copy_mu);
+        if (hipStreamQuery(s.stream) != hipSuccess) {  // back-to-back submits on one slot: its buffers are still being read
+            (void) hipGetLastError();                  // hipErrorNotReady is not an error
+            HIPCHK(ctx, hipEventRecord(s.ev_tail, s.stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, s.ev_tail, 0));
+        }
+        return 0;
+    }
+    int copy(void *dst, const void *src, u64 bytes) {
+        HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        return 0;
+    }
+    int end() {
+        HIPCHK(ctx, hipEventRecord(s.ev_copied, ctx->copy_stream));
+        lk.unlock();
+        HIPCHK(ctx, hipStreamWaitEvent(s.stream, s.ev_copied, 0));
+        return 0;
+    }
+};
+
 static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevBatch *db) {
     if (b->n_reads > ctx->p.max_batch_reads) return fail(ctx, "batch has more reads than max_batch_reads");
     if (ctx->p.mode == TREW_MODE_PAIR && (b->n_reads & 1)) return fail(ctx, "pair mode needs an even number of reads");
@@ -411,30 +460,35 @@ static int stage_batch(trew_hip_ctx *ctx, const trew_hip_batch *b, Slot &s, DevB
         }
         // The caller laid the three arrays out back to back in one buffer (see trew_hip.h): ONE copy.  A host that
         // submits thousands of batches a second is bound by HIP API calls, not by bytes.
+        BatchCopy bc(ctx, s);
+        if (int rc = bc.begin()) return rc;
         if (b->offsets && b->lengths == b->offsets + b->n_reads && b->words == b->lengths + b->n_reads) {  // [offsets][lengths][words]
-            HIPCHK(ctx, hipMemcpyAsync(s.d_buf, b->offsets, (2 * b->n_reads + b->n_words) * 4, hipMemcpyHostToDevice, s.stream));
+            if (int rc = bc.copy(s.d_buf, b->offsets, (2 * b->n_reads + b->n_words) * 4)) return rc;
+            if (int rc = bc.end()) return rc;
             db->offsets = s.d_buf;
             db->lengths = s.d_buf + b->n_reads;
             db->words = s.d_buf + 2 * b->n_reads;
             return 0;
         }
         if (b->offsets && b->offsets == b->words + b->n_words && b->lengths == b->offsets + b->n_reads) {  // [words][offsets][lengths]
-            HIPCHK(ctx, hipMemcpyAsync(s.d_buf, b->words, (2 * b->n_reads + b->n_words) * 4, hipMemcpyHostToDevice, s.stream));
+            if (int rc = bc.copy(s.d_buf, b->words, (2 * b->n_reads + b->n_words) * 4)) return rc;
+            if (int rc = bc.end()) return rc;
             db->words = s.d_buf;
             db->offsets = s.d_buf + b->n_words;
             db->lengths = s.d_buf + b->n_words + b->n_reads;
             return 0;
         }
-        HIPCHK(ctx, hipMemcpyAsync(s.d_words, b->words, b->n_words * 4, hipMemcpyHostToDevice, s.stream));
+        if (int rc = bc.copy(s.d_words, b->words, b->n_words * 4)) return rc;
         db->words = s.d_words;
         db->offsets = nullptr;
         db->lengths = nullptr;
         if (b->offsets) {
-            HIPCHK(ctx, hipMemcpyAsync(s.d_offsets, b->offsets, b->n_reads * 4, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(ctx, hipMemcpyAsync(s.d_lengths, b->lengths, b->n_reads * 4, hipMemcpyHostToDevice, s.stream));
+            if (int rc = bc.copy(s.d_offsets, b->offsets, b->n_reads * 4)) return rc;
+            if (int rc = bc.copy(s.d_lengths, b->lengths, b->n_reads * 4)) return rc;
             db->offsets = s.d_offsets;
             db->lengths = s.d_lengths;
         }
+        if (int rc = bc.end()) return rc;
     }
     return 0;
 }
@@ -502,9 +556,7 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
     const u32 cap = std::max<u32>(64u, ((exact_seg + 1 + 63u) / 64u) * 64u);
     const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
-    DevTable tbl = ctx->table;
-    if (ctx->p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;
-    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, tbl, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
+    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->d_table, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
     if (timed) SUBMIT_CHK(hipEventRecord(ev[2], s.stream));
 #undef SUBMIT_CHK
     s.n_launches++;
@@ -567,21 +619,27 @@ static int stage_ascii(trew_hip_ctx *ctx, const trew_hip_ascii_batch *a, Slot &s
         d_bases = s.d_ascii + 12ull * a->n_reads;
         const bool one = a->byte_offsets == a->word_offsets + a->n_reads && a->lengths == a->byte_offsets + a->n_reads &&
                          (const void *) a->bases == (const void *) (a->lengths + a->n_reads);
+        BatchCopy bc(ctx, s);
+        if (int rc = bc.begin()) return rc;
         if (one) {  // [word_offsets][byte_offsets][lengths][bases] in one pinned buffer: ONE copy
-            HIPCHK(ctx, hipMemcpyAsync(s.d_ascii, a->word_offsets, 12ull * a->n_reads + a->n_bytes, hipMemcpyHostToDevice, s.stream));
+            if (int rc = bc.copy(s.d_ascii, a->word_offsets, 12ull * a->n_reads + a->n_bytes)) return rc;
         } else {
-            HIPCHK(ctx, hipMemcpyAsync(arr, a->word_offsets, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(ctx, hipMemcpyAsync(arr + a->n_reads, a->byte_offsets, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(ctx, hipMemcpyAsync(arr + 2 * a->n_reads, a->lengths, 4ull * a->n_reads, hipMemcpyHostToDevice, s.stream));
-            HIPCHK(ctx, hipMemcpyAsync(s.d_ascii + 12ull * a->n_reads, a->bases, a->n_bytes, hipMemcpyHostToDevice, s.stream));
+            if (int rc = bc.copy(arr, a->word_offsets, 4ull * a->n_reads)) return rc;
+            if (int rc = bc.copy(arr + a->n_reads, a->byte_offsets, 4ull * a->n_reads)) return rc;
+            if (int rc = bc.copy(arr + 2 * a->n_reads, a->lengths, 4ull * a->n_reads)) return rc;
+            if (int rc = bc.copy(s.d_ascii + 12ull * a->n_reads, a->bases, a->n_bytes)) return rc;
         }
+        if (int rc = bc.end()) return rc;
         db->offsets = d_wo;
         db->lengths = d_len;
         db->uniform_length = 0;
         db->uniform_stride = 0;
     } else {
         d_bases = s.d_ascii;
-        HIPCHK(ctx, hipMemcpyAsync(s.d_ascii, a->bases, a->n_reads * (u64) a->uniform_length, hipMemcpyHostToDevice, s.stream));
+        BatchCopy bc(ctx, s);
+        if (int rc = bc.begin()) return rc;
+        if (int rc = bc.copy(s.d_ascii, a->bases, a->n_reads * (u64) a->uniform_length)) return rc;
+        if (int rc = bc.end()) return rc;
         db->offsets = nullptr;
         db->lengths = nullptr;
         db->uniform_length = a->uniform_length;
