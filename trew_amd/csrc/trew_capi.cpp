@@ -88,6 +88,7 @@ struct trew_hip_ctx {
     // TREW_FLAG_TRACK_PRESSURE: the largest value of each fill counter any host thread has read so far (they only grow
     // between resets); trew_hip_table_pressure answers from these
     std::atomic<u32> seen[kDiagWords];
+    std::atomic<int> last_slot{-1};  // slot of the most recent submit (launch_batch: is another slot's batch still running?)
     std::mutex seen_mu;  // keeps a reset (which zeroes the copies) apart from a query that folds them
 };
 
@@ -556,7 +557,15 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
     const u32 exact_seg = ctx->p.mode == TREW_MODE_LONG ? std::min<u32>(max_len, (u32) (2 * ctx->dp.slice_len - 1)) : max_len;
     const u32 cap = std::max<u32>(64u, ((exact_seg + 1 + 63u) / 64u) * 64u);
     const u32 rawwords = ctx->p.mode == TREW_MODE_LONG ? 4u : 3u * ((max_len + 31u) / 32u) + 1u;
-    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->d_table, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg));
+    // is the previous submit (on another slot) still running?  Then this batch's kernels will share the chip with it.
+    const int me = (int) (&s - ctx->slots.data());
+    const int prev = ctx->last_slot.exchange(me, std::memory_order_relaxed);
+    bool share = false;
+    if (prev >= 0 && prev != me) {
+        share = hipStreamQuery(ctx->slots[(size_t) prev].stream) == hipErrorNotReady;
+        (void) hipGetLastError();
+    }
+    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->d_table, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg, share));
     if (timed) SUBMIT_CHK(hipEventRecord(ev[2], s.stream));
 #undef SUBMIT_CHK
     s.n_launches++;

@@ -106,14 +106,15 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
     typedef void (*kern_t)(DevParams, DevBatch, u32 *, u32 *, u32, u64 *, int, int, u32 *, const int2 *);
     const kern_t fn = nw == 3 ? filter_kernel<3> : nw == 5 ? filter_kernel<5> : nw == 10 ? filter_kernel<10> : filter_kernel<32>;
     const u32 threads = kFilterThreads;
-    // Persistent blocks with a static, grid-strided share of the reads each; twice the resident number of blocks
-    // (78 VGPRs -> 6 waves per SIMD for 150-bp reads), so that CUs whose blocks finish early pick up another one.
+    // Persistent blocks that pull chunks of reads from the device queue; as many as are resident at once (78 VGPRs -> 6 waves
+    // per SIMD for 150-bp reads).  (Twice that number -- a relic of the static, grid-strided partition -- only put blocks in
+    // the dispatcher's queue that find the chunk queue empty, and took wave slots from a co-resident exact kernel of the other
+    // stream: step 1.038 -> 1.018 ms with the resident number, profiles/r03/README.md.)
     static thread_local kern_t cached_fn = nullptr;
     static thread_local int cached_per_cu = 0;
     int per_cu = cached_per_cu;
     if (cached_fn != fn) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *) fn, (int) threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        per_cu *= 2;
         if (const char *e = getenv("TREW_FILTER_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments only
         cached_fn = fn;
         cached_per_cu = per_cu;
@@ -135,7 +136,7 @@ u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_ld
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable *T,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
-                        u32 max_seg_len) {
+                        u32 max_seg_len, bool share) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words
     const bool wide = P.max_mer > 32;  // 128-bit words, k_mer_check_128 (kmer.cpp:100, 180)
     const u32 lds = exact_lds_bytes(cap, rawwords, wide ? 16u : 8u);
@@ -186,6 +187,13 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
         cached_per_cu = per_cu;
     }
     per_cu = per_cu > 32 ? 32 : per_cu;
+    // share: another slot's batch is in flight, i.e. a prefilter will run beside this kernel.  Both are persistent: whoever
+    // starts first holds every wave slot until its queue runs dry, and the other only fills the tail.  Half the slots each
+    // keeps both resident from start to end (measured, 10 M reads a step, two streams: 1.048 -> 0.989 ms; pair mode
+    // 11.14 -> 11.04 ms; long reads, where the prefilter is a quarter of the work, are better off with the whole chip:
+    // 3.60 against 3.69 ms -- profiles/r03/README.md).
+    if (share && P.mode != TREW_MODE_LONG) per_cu = std::max(1, per_cu / 2);
+    if (const char *e = getenv("TREW_EXACT_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments only
     // Self-scheduling waves: any grid size is correct, it only has to be large enough to keep the chip busy.  A big
     // batch gets every resident wave slot; a small one (the CLI's ~10^5-read batches, of which 1-2 % survive the
     // prefilter) one wave per 16 units, so that a launch does not start thousands of waves that find the queue empty.

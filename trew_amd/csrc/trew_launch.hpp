@@ -13,7 +13,7 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
 void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table);  // kMaxSlots * kThrRow entries
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable *d_table,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
-                        u32 max_seg_len);
+                        u32 max_seg_len, bool share);  // share: leave half of the wave slots to a prefilter on another stream
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes);
 hipError_t fallback_counters_read(u32 *out);  // kFallbackWords words of the current device
 hipError_t fallback_counters_clear();
