@@ -59,6 +59,12 @@ enum {
                                   wait counts as timed out (trew_hip_debug_counters), duplicates are left for collect to merge */
     TREW_FLAG_NO_TIMING = 64, /* no HIP events around the kernels (trew_hip_last_timing is unavailable): for hosts that
                                 submit ~10^4 small batches a second and are bound by API calls */
+    TREW_FLAG_COMPAT_G1 = 512, /* pair mode, MAX_MER <= 32, n_slots = 1 only: follow the reference's 64-bit pair branch as written --
+                                temp_result_left is not cleared after the whole-read block (kmer.cpp:467-505; the 128-bit twin
+                                clears it, 722-723), so what that block recorded is added once more by the next pair: to `both`
+                                if that pair's four segments chain, else to `forward` (kmer.cpp:378-399, 438-455).  Batches must
+                                be submitted in file order; this reproduces the reference run with ONE consumer thread (with
+                                more its output depends on scheduling).  Default: the cleared semantics. */
     TREW_FLAG_TRACK_PRESSURE = 256 /* every batch ends with a copy of the table's fill counters into pinned host memory, and
                                 trew_hip_table_pressure answers from those copies (and from what collect / add_rows /
                                 reset read since) instead of asking the device: for hosts that ask before every batch.

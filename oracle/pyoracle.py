@@ -28,6 +28,7 @@ class _Params(C.Structure):
         ("high", C.c_double),
         ("slice_len", C.c_int),
         ("use_break", C.c_int),
+        ("compat_g1", C.c_int),
     ]
 
 
@@ -49,9 +50,10 @@ class OracleParams:
     high: float = 0.8
     slice_len: int = 150
     use_break: bool = True
+    compat_g1: bool = False  # pairs: the 64-bit branch's un-cleared temp_result_left, one context, file order
 
     def c(self) -> _Params:
-        return _Params(self.min_mer, self.max_mer, self.low, self.high, self.slice_len, 1 if self.use_break else 0)
+        return _Params(self.min_mer, self.max_mer, self.low, self.high, self.slice_len, 1 if self.use_break else 0, 1 if self.compat_g1 else 0)
 
 
 def build(force: bool = False) -> str:

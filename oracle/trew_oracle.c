@@ -295,8 +295,10 @@ void trew_oracle_add_short(trew_oracle_ctx *c, const char *buf, const int64_t *s
  * temp_result_left after the whole-read block (467-505) while its 128-bit twin
  * does (722-723); the stale entries leak into the next pair handled by the same
  * worker thread (a reference bug that makes results depend on thread
- * scheduling).  This restatement implements the cleared (128-bit twin)
- * semantics -- the one documented divergence; it cannot trigger when
+ * scheduling).  By default this restatement implements the cleared (128-bit twin)
+ * semantics; with params.compat_g1 the 64-bit branch is followed as written (the
+ * lists tl[] live in the context, so the entries reach the next pair exactly as
+ * temp_result_left does in a single consumer thread).  It cannot trigger when
  * min(n1,n2) >= 4*MAX_MER. */
 void trew_oracle_add_pair(trew_oracle_ctx *c, const char *buf1, const int64_t *st1v, const int64_t *nd1v,
                           const char *buf2, const int64_t *st2v, const int64_t *nd2v, int64_t npairs) {
@@ -394,8 +396,10 @@ void trew_oracle_add_pair(trew_oracle_ctx *c, const char *buf1, const int64_t *s
                         flush_canon(c, &tl[b], b == 0 ? TREW_T_BOTH_HIGH : TREW_T_BOTH_LOW);
                 flush(c, &tl[0], TREW_T_FORWARD_HIGH);
                 flush(c, &tl[1], TREW_T_FORWARD_LOW);
-                rlist_clear(&tl[0]); /* the 128-bit twin's clear, kmer.cpp:722-723 */
-                rlist_clear(&tl[1]);
+                if (!(c->p.compat_g1 && MAX_MER <= 32)) { /* the 128-bit twin's clear, kmer.cpp:722-723; the 64-bit branch has none */
+                    rlist_clear(&tl[0]);
+                    rlist_clear(&tl[1]);
+                }
             }
         }
     }

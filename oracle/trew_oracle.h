@@ -45,6 +45,10 @@ typedef struct {
     double high;      /* HIGH_BASELINE (-H, default 0.8) */
     int slice_len;    /* SLICE_LENGTH (-s, long mode, default 150) */
     int use_break;    /* 1 = keep the reference's early break (kmer.cpp:2207-2210) */
+    int compat_g1;    /* 1 = the 64-bit pair branch as written: temp_result_left is NOT cleared after the whole-read block
+                         (kmer.cpp:467-505), so its entries are added once more by the next pair this context is given
+                         (SURVEY G1).  Pairs must then be added in file order to ONE context: that is the reference with a
+                         single consumer thread.  No effect for MAX_MER > 32 (the 128-bit twin clears, kmer.cpp:722-723). */
 } trew_oracle_params;
 
 /* one (k, word) -> count row; word is the 2k-bit k-mer, first base most
@@ -87,7 +91,7 @@ trew_oracle_ctx *trew_oracle_new(const trew_oracle_params *p);
 void trew_oracle_free(trew_oracle_ctx *c);
 /* short single-end: buffer_task kmer.cpp:111-173 */
 void trew_oracle_add_short(trew_oracle_ctx *c, const char *buf, const int64_t *st, const int64_t *nd, int64_t n);
-/* short paired-end: buffer_task_pair kmer.cpp:322-507 (with the 128-bit twin's clear, 722-723) */
+/* short paired-end: buffer_task_pair kmer.cpp:322-507 (with the 128-bit twin's clear, 722-723, unless compat_g1) */
 void trew_oracle_add_pair(trew_oracle_ctx *c, const char *buf1, const int64_t *st1, const int64_t *nd1,
                           const char *buf2, const int64_t *st2, const int64_t *nd2, int64_t n);
 /* long: buffer_task_long kmer.cpp:785-871 */

@@ -113,6 +113,28 @@ def test_cli_pair(tmp_path):
     assert run("short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2, "-t", "4") == want
 
 
+def test_cli_pair_compat_g1(tmp_path):
+    """--compat_g1: `trew short --paired_end` with the reference's un-cleared temp_result_left (kmer.cpp:467-505),
+    one consumer in file order -- the oracle with compat_g1 on the same pairs, from both readers and with small batches (the
+    stale rows cross batch boundaries); without the flag the cleared semantics; with MAX_MER > 32 the flag changes nothing
+    (the reference's 128-bit branch clears the map, kmer.cpp:722-723)."""
+    from test_gpu_parity import _g1_pairs
+
+    r1, r2 = _g1_pairs(9, 3000)
+    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    write_fastq(f1, r1)
+    write_fastq(f2, r2)
+    want = expected([(f1, O.run_pair(O.OracleParams(compat_g1=True), r1, r2))], 5)
+    cleared = expected([(f1, O.run_pair(O.OracleParams(), r1, r2))], 5)
+    assert want != cleared
+    base = ["short", "5", "32", "--paired_end", "--fq1", f1, "--fq2", f2]
+    for extra in (["-t", "4"], ["-t", "2", "--serial_reader"], ["-t", "8", "--batch_mib", "1"]):
+        assert run(*base, "--compat_g1", *extra) == want, extra
+    assert run(*base, "-t", "4") == cleared
+    wide = expected([(f1, O.run_pair(O.OracleParams(max_mer=40), r1, r2))], 5)
+    assert run("short", "5", "40", "--paired_end", "--fq1", f1, "--fq2", f2, "--compat_g1") == wide
+
+
 def test_cli_pair_block_parallel(tmp_path):
     """Two plain files: the paired block reader (mates located by read index from per-block newline counts, read ranges
     claimed by the workers) against the oracle and against the reference-shaped serial reader; mates of different lengths,

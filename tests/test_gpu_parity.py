@@ -420,6 +420,85 @@ def test_pair_parity_edge_pairs():
     _pair_parity(r1, r2, min_mer=3, max_mer=12)
 
 
+def _g1_pairs(seed, count):
+    """Pairs that make the whole-read block of buffer_task_pair record something (a period too long for a quarter of the read:
+    the halves find nothing, the whole read does), between pairs of every kind that can follow them: fully chained telomeric
+    pairs, random pairs, pairs shorter than 4 * MIN_MER (their four-segment block is skipped and the stale map survives them),
+    pairs below 2 * MIN_MER (skipped altogether), mates of unequal length, an N here and there."""
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(seed)
+    r1, r2 = [], []
+
+    def rand(n):
+        return "".join(rnd.choice("ACGT") for _ in range(n))
+
+    for _ in range(count):
+        kind = rnd.random()
+        n1 = rnd.choice([100, 100, 100, 90, 120, 127, 64, 110])
+        n2 = rnd.choice([n1, n1, 100, 110])
+        if kind < 0.35:  # whole-read-only repeat on one or both mates
+            k = rnd.randint(min(n1, n2) // 4 + 1, min(32, min(n1, n2) // 2))
+            unit = rand(k)
+            a = mutate(periodic(unit, n1, rnd.randint(0, k - 1)), rnd, p_sub=rnd.choice([0.0, 0.0, 0.02]), p_n=rnd.choice([0.0, 0.0, 0.01]))
+            b = _revcomp(periodic(unit, n2, rnd.randint(0, k - 1)).encode()).decode() if rnd.random() < 0.5 else rand(n2)
+        elif kind < 0.5:  # fully chained telomeric pair
+            frag = periodic(rnd.choice(["TTAGGG", "CCCTAA", "TTTAGGG"]), n1 + n2, rnd.randint(0, 5))
+            a, b = frag[:n1], _revcomp(frag[n1:].encode()).decode()
+        elif kind < 0.6:  # telomeric on the first mate only
+            a, b = periodic("TTAGGG", n1, rnd.randint(0, 5)), rand(n2)
+        elif kind < 0.75:  # shorter than 4 * MIN_MER: no four-segment block
+            m = rnd.randint(10, 19)
+            u = rand(rnd.randint(5, m // 2))
+            a, b = periodic(u, m + rnd.randint(0, 3)), (periodic(u, m) if rnd.random() < 0.5 else _revcomp(periodic(u, m).encode()).decode())
+        elif kind < 0.8:  # below 2 * MIN_MER: skipped
+            a, b = rand(rnd.randint(1, 9)), rand(rnd.randint(1, 30))
+        else:
+            a, b = rand(n1), rand(n2)
+        r1.append(a.encode())
+        r2.append(b.encode())
+    return r1, r2
+
+
+def test_pair_compat_g1_reproduces_the_uncleared_map():
+    """TREW_FLAG_COMPAT_G1: the reference's 64-bit pair branch as written (kmer.cpp:467-505 has no clear of temp_result_left;
+    its 128-bit twin has, 722-723) for one consumer thread -- against the oracle run with compat_g1 on the same pairs in the same
+    order, as one batch and cut into batches at every size (rows of a batch's last pairs reach the next batch through the carry),
+    for two k ranges; and the flag changes the tables (the test has teeth), while a context without it still gives the cleared
+    semantics."""
+    r1, r2 = _g1_pairs(5, 700)
+    for kw in ({}, {"min_mer": 3, "max_mer": 12}):
+        p = O.OracleParams(compat_g1=True, **kw)
+        want = O.run_pair(p, r1, r2)
+        cleared = O.run_pair(O.OracleParams(**kw), r1, r2)
+        assert want != cleared and sum(want["forward_high"].values()) > sum(cleared["forward_high"].values())
+        assert sum(want["both_low"].values()) > sum(cleared["both_low"].values())  # stale rows that met a fully chained pair
+        reads = [x for ab in zip(r1, r2) for x in ab]
+        for per_batch in (len(r1), 1, 7, 64):
+            with T.TrewHip(mode=T.MODE_PAIR, n_slots=1, max_batch_reads=2 * len(r1) + 8, max_batch_words=1 << 21, flags=T.FLAG_COMPAT_G1, **kw) as t:
+                for at in range(0, len(r1), per_batch):
+                    t.submit_reads(reads[2 * at:2 * (at + per_batch)])
+                    t.wait()
+                got = t.collect()
+                for name in T.TABLE_NAMES:
+                    assert got[name] == want[name], (kw, per_batch, name)
+                # a second input on the same context starts with an empty map
+                t.reset_tables()
+                t.submit_reads(reads)
+                t.wait()
+                assert t.collect() == want
+        with T.TrewHip(mode=T.MODE_PAIR, n_slots=1, max_batch_reads=2 * len(r1) + 8, max_batch_words=1 << 21, **kw) as t:
+            t.submit_reads(reads)
+            t.wait()
+            assert t.collect() == cleared
+    # the flag is refused where it cannot mean anything
+    for bad in (dict(mode=T.MODE_SHORT, n_slots=1), dict(mode=T.MODE_PAIR, n_slots=2), dict(mode=T.MODE_PAIR, n_slots=1, max_mer=40)):
+        with pytest.raises(T.TrewHipError, match="COMPAT_G1"):
+            T.TrewHip(flags=T.FLAG_COMPAT_G1, **bad)
+
+
 # ---------------------------------------------------------------- long reads (buffer_task_long)
 def _long_reads(seed, count):
     import random

@@ -18,6 +18,7 @@ MODE_SHORT, MODE_PAIR, MODE_LONG, MODE_SEGMENT = 0, 1, 2, 3
 FLAG_NO_FILTER = 1
 FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (tests)
 FLAG_NO_TIMING = 64  # no HIP events per submit (last_timing unavailable)
+FLAG_COMPAT_G1 = 512  # pair mode, one slot: the reference's 64-bit pair branch as written (un-cleared temp_result_left)
 FLAG_TRACK_PRESSURE = 256  # the fill counters come back with every batch; table_pressure asks no device
 FLAG_DEBUG_WIDE_NO_WAIT = 128  # tests: the wide table never waits for a slot's ready bit (forces its time-out path)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")

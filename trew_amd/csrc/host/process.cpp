@@ -210,7 +210,11 @@ Scanner *scanner_create(const Config &cfg, int mode) {
     Scanner *s = new Scanner();
     s->cfg = cfg;
     s->mode = mode;
-    const int n_workers = std::max(1, cfg.NUM_THREAD - 1);  // the caller's thread is the reader (kmer.cpp:1278-1301)
+    // --compat_g1: the reference's 64-bit pair branch with its un-cleared temp_result_left is only defined for ONE
+    // consumer that sees the pairs in file order: one worker, one slot.  With MAX_MER > 32 the reference runs the 128-bit
+    // branch, which clears the map: nothing to reproduce, the flag is not passed on.
+    const bool compat_g1 = cfg.compat_g1 && mode == TREW_MODE_PAIR && cfg.MAX_MER <= 32;
+    const int n_workers = compat_g1 ? 1 : std::max(1, cfg.NUM_THREAD - 1);  // the caller's thread is the reader (kmer.cpp:1278-1301)
     const int ndev = (int) cfg.devices.size();
     const bool pair = mode == TREW_MODE_PAIR;
     const uint64_t reads_cap = (pair ? 2ull : 1ull) << 20;
@@ -231,14 +235,14 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         p.slice_length = cfg.SLICE_LENGTH;
         p.mode = mode;
         p.device = cfg.devices[(size_t) d];
-        p.n_slots = 2 * std::max(1, slots_on_dev[(size_t) d]);
+        p.n_slots = compat_g1 ? 1 : 2 * std::max(1, slots_on_dev[(size_t) d]);
         p.max_batch_words = words_cap;
         p.max_batch_reads = reads_cap;
         p.table_log2_slots = (uint32_t) cfg.table_log2_slots;
         p.max_batch_ascii_bytes = cfg.host_pack ? 0 : text_cap;
         // ~10^4 small batches a second: every HIP call per batch counts -- no timing events, and the table's fill state comes
         // back with every batch instead of being asked for before every batch (0.4 ms a query with 15 threads asking)
-        p.flags = TREW_FLAG_NO_TIMING | TREW_FLAG_TRACK_PRESSURE;
+        p.flags = TREW_FLAG_NO_TIMING | TREW_FLAG_TRACK_PRESSURE | (compat_g1 ? TREW_FLAG_COMPAT_G1 : 0);
         trew_hip_ctx *c = nullptr;
         if (trew_hip_init(&p, &c) != 0) die(trew_hip_last_error(nullptr));
         s->dev.emplace_back(new Device());
@@ -249,7 +253,7 @@ Scanner *scanner_create(const Config &cfg, int mode) {
         Worker wk;
         wk.dev_index = w % ndev;
         wk.slot = next_slot[(size_t) wk.dev_index]++;
-        wk.slot_b = next_slot[(size_t) wk.dev_index]++;
+        wk.slot_b = compat_g1 ? wk.slot : next_slot[(size_t) wk.dev_index]++;
         wk.words_cap = words_cap;
         wk.reads_cap = reads_cap;
         trew_hip_ctx *c = s->dev[(size_t) wk.dev_index]->ctx;
@@ -324,6 +328,9 @@ static void submit_packed(Scanner *s, Worker *w, uint32_t *h_words, uint32_t *h_
     const bool pressed = under_pressure(c);
     w->t_pressure += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
     if (pressed) {
+        // emptying the table mid-file also empties the stale map of --compat_g1 (trew_hip_reset_tables starts a new input): say so
+        if (s->cfg.compat_g1 && s->mode == TREW_MODE_PAIR && s->cfg.MAX_MER <= 32)
+            die("--compat_g1: the device count table filled up in the middle of a file; raise --table_log2_slots");
         std::unique_lock<std::shared_mutex> lk(d->drain_mu);  // waits for running submits, blocks new ones
         if (under_pressure(c)) {                              // nobody drained in the meantime
             drain_device(s, d);
@@ -354,6 +361,9 @@ static void submit_text(Scanner *s, Worker *w, const trew_hip_ascii_batch &b, ui
     const bool pressed = under_pressure(c);
     w->t_pressure += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
     if (pressed) {
+        // emptying the table mid-file also empties the stale map of --compat_g1 (trew_hip_reset_tables starts a new input): say so
+        if (s->cfg.compat_g1 && s->mode == TREW_MODE_PAIR && s->cfg.MAX_MER <= 32)
+            die("--compat_g1: the device count table filled up in the middle of a file; raise --table_log2_slots");
         std::unique_lock<std::shared_mutex> lk(d->drain_mu);  // waits for running submits, blocks new ones
         if (under_pressure(c)) {                              // nobody drained in the meantime
             drain_device(s, d);

@@ -3,7 +3,7 @@
 // Same sub-commands, positional arguments, options, limits and messages as the reference CLI
 // (trew.cpp:22-478): stdout carries the CSV sections, stderr errors/usage, exit code 1 on error.
 // Additions (stderr only, stdout stays CSV-identical): --devices LIST, --stats, --table_log2_slots N,
-// --serial_reader, --batch_mib N, --host_pack.
+// --serial_reader, --batch_mib N, --host_pack, --compat_g1.
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +28,7 @@ static void usage(const char *mode) {
                 "Usage: short [--help] [--version] [--thread THREAD] [--paired_end] [--fq1 FASTQ_FRONT...] [--fq2 FASTQ_REVERSE...]\n"
                 "             [--table_max_mer TABLE_MAX_MER] [--low_baseline LOW_BASELINE] [--high_baseline HIGH_BASELINE]\n"
                 "             [--queue_size QUEUE_SIZE] [--devices LIST] [--stats] [--table_log2_slots N] [--serial_reader]\n"
-                "             [--batch_mib N] [--host_pack] MIN_MER MAX_MER [SHORT_FASTQ]...\n\n"
+                "             [--batch_mib N] [--host_pack] [--compat_g1] MIN_MER MAX_MER [SHORT_FASTQ]...\n\n"
                 "Estimate TRM from short-read sequencing data.\n");
     } else {
         fprintf(stderr, "Usage: trew [--help] [--version] {long,short}\n\nSubcommands:\n  long          Estimate TRM from long-read sequencing data.\n"
@@ -145,6 +145,9 @@ int main(int argc, char **argv) {
             cfg.serial_reader = true;
         } else if (a == "--host_pack") {
             cfg.host_pack = true;
+        } else if (IS_SHORT && a == "--compat_g1") {
+            multi = nullptr;
+            cfg.compat_g1 = true;
         } else if (a == "--batch_mib") {
             multi = nullptr;
             ok = parse_int(need("--batch_mib"), &cfg.batch_mib) && cfg.batch_mib >= 1 && cfg.batch_mib <= 32;

@@ -64,7 +64,13 @@ struct trew_hip_ctx {
     trew_hip_params p;
     DevParams dp;
     DevTable table;
-    DevTable *d_table = nullptr;  // device copy of `table` for the exact kernels, which take it by pointer (exact_core.inc, TableRef)
+    DevTable *d_table = nullptr;  // device copy of `table` (a DevTableG1) for the exact kernels, which take it by pointer (exact_core.inc, TableRef)
+    // TREW_FLAG_COMPAT_G1 (kernels/g1_compat.inc): the stale-row log, the pair flags and the two carry buffers (read / written
+    // by a batch, swapped after it)
+    DevG1 g1 = {nullptr, nullptr, nullptr, 0};
+    trew_hip_row *g1_carry[2] = {nullptr, nullptr};
+    u32 g1_carry_cap = 0;
+    u64 g1_batches = 0;
     DevWide wide;  // host copy of *table.wide
     u64 table_slots = 0;
     std::vector<Slot> slots;
@@ -172,6 +178,10 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         if (p.slice_length < 2 * p.max_mer) { g_init_error = "SLICE_LENGTH must be greater than or equal to twice of MAX_MER."; return -1; }
         if (2 * p.slice_length - 1 > kMaxSegBases) { g_init_error = "SLICE_LENGTH must be at most 512 on the HIP path."; return -1; }
     }
+    if ((p.flags & TREW_FLAG_COMPAT_G1) && (p.mode != TREW_MODE_PAIR || p.max_mer > 32 || p.n_slots != 1)) {
+        g_init_error = "TREW_FLAG_COMPAT_G1 needs pair mode, MAX_MER <= 32 (the 128-bit branch has no stale map) and n_slots = 1 (file order)";
+        return -1;
+    }
     if (p.n_slots < 1 || p.n_slots > 512) { g_init_error = "n_slots must be in [1,512]"; return -1; }
     if (p.table_log2_slots < 12 || p.table_log2_slots > 30) { g_init_error = "table_log2_slots must be in [12,30]"; return -1; }
     if (p.max_batch_reads == 0 || p.max_batch_reads > 0xfffffff0ull) { g_init_error = "max_batch_reads out of range"; return -1; }
@@ -235,10 +245,24 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         ctx->table.wide = dw;
     }
     {
-        DevTable tbl = ctx->table;
-        if (p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.log2_part_slots = 0xffffffffu;  // cached_add drops every row
-        if ((e = hipMalloc((void **) &ctx->d_table, sizeof(DevTable))) != hipSuccess) return bail("hipMalloc(table descriptor)", e);
-        if ((e = hipMemcpy(ctx->d_table, &tbl, sizeof(DevTable), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+        if (p.flags & TREW_FLAG_COMPAT_G1) {
+            // a pair's whole-read block records the classes of at most two reads for two baselines; the log is sized for
+            // every pair of a full batch doing so with a dozen classes each and reports (never hides) an overflow
+            ctx->g1.log_cap = (u32) std::min<u64>(std::max<u64>(1ull << 16, 24ull * (p.max_batch_reads / 2)), 1ull << 26);
+            ctx->g1_carry_cap = 1u << 16;
+            if ((e = hipMalloc((void **) &ctx->g1.log, (size_t) ctx->g1.log_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(G1 log)", e);
+            if ((e = hipMalloc((void **) &ctx->g1.counters, 16)) != hipSuccess) return bail("hipMalloc(G1 counters)", e);
+            if ((e = hipMemset(ctx->g1.counters, 0, 16)) != hipSuccess) return bail("hipMemset", e);
+            if ((e = hipMalloc((void **) &ctx->g1.pair_flags, (size_t) (p.max_batch_reads / 2 + 64))) != hipSuccess) return bail("hipMalloc(G1 pair flags)", e);
+            for (auto &cb : ctx->g1_carry)
+                if ((e = hipMalloc((void **) &cb, (size_t) ctx->g1_carry_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(G1 carry)", e);
+        }
+        DevTableG1 tbl;
+        tbl.t = ctx->table;
+        tbl.g = ctx->g1;
+        if (p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.t.log2_part_slots = 0xffffffffu;  // cached_add drops every row
+        if ((e = hipMalloc((void **) &ctx->d_table, sizeof(DevTableG1))) != hipSuccess) return bail("hipMalloc(table descriptor)", e);
+        if ((e = hipMemcpy(ctx->d_table, &tbl, sizeof(DevTableG1), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
     }
 
     if ((e = hipMalloc((void **) &ctx->d_row_flags, kRowFlagWords * 4)) != hipSuccess) return bail("hipMalloc(row flags)", e);
@@ -320,6 +344,11 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->wide.spill_rows) (void) hipFree(ctx->wide.spill_rows);
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
     if (ctx->d_table) (void) hipFree(ctx->d_table);
+    if (ctx->g1.log) (void) hipFree(ctx->g1.log);
+    if (ctx->g1.counters) (void) hipFree(ctx->g1.counters);
+    if (ctx->g1.pair_flags) (void) hipFree(ctx->g1.pair_flags);
+    for (auto cb : ctx->g1_carry)
+        if (cb) (void) hipFree(cb);
     if (ctx->d_collect_n) (void) hipFree(ctx->d_collect_n);
     if (ctx->d_collect_rows) (void) hipFree(ctx->d_collect_rows);
     if (ctx->d_add_rows) (void) hipFree(ctx->d_add_rows);
@@ -547,6 +576,8 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
     } while (0)
     const int2 *d_thr = nullptr;
     if (int rc = stage_thresholds(ctx, s, db, &d_thr)) return submit_failed(rc);
+    const bool compat_g1 = (ctx->p.flags & TREW_FLAG_COMPAT_G1) != 0;
+    if (compat_g1) SUBMIT_CHK(hipMemsetAsync(ctx->g1.pair_flags, 0, db.n_units, s.stream));
     const bool timed = !(ctx->p.flags & TREW_FLAG_NO_TIMING);
     hipEvent_t *ev = s.ev[s.n_submits % Slot::kRing];
     if (timed) SUBMIT_CHK(hipEventRecord(ev[0], s.stream));
@@ -567,6 +598,11 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
     }
     SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->d_table, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg, share));
     if (timed) SUBMIT_CHK(hipEventRecord(ev[2], s.stream));
+    if (compat_g1) {  // the stale rows of this batch's pairs (and of the previous batch's tail) are added again, in file order
+        SUBMIT_CHK(launch_g1_apply(s.stream, ctx->table, ctx->g1, db, ctx->dp.min_mer, ctx->g1_carry[ctx->g1_batches & 1], ctx->g1_carry[(ctx->g1_batches + 1) & 1],
+                                   ctx->g1_carry_cap));
+        ctx->g1_batches++;
+    }
 #undef SUBMIT_CHK
     s.n_launches++;
     s.n_submits++;
@@ -715,6 +751,7 @@ static int check_diag(trew_hip_ctx *ctx, u32 (&diag)[kDiagWords]) {
     if (diag[kDiagOverflow]) return fail(ctx, "device count table and its spill log are full: raise table_log2_slots");
     if (diag[kDiagWorklistDrop]) return fail(ctx, "internal error: the prefilter worklist overflowed (survivors were dropped)");
     if (diag[kDiagIntentDrop]) return fail(ctx, "internal error: a pair logged more than 32 deferred emissions (some were dropped)");
+    if (diag[kDiagG1Drop]) return fail(ctx, "TREW_FLAG_COMPAT_G1: the stale-row log of a batch overflowed (submit smaller batches)");
     return 0;
 }
 
@@ -829,6 +866,7 @@ static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
     HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
     HIPCHK(ctx, fallback_counters_clear());
+    if (ctx->g1.counters) HIPCHK(ctx, hipMemset(ctx->g1.counters, 0, 16));  // a new input: nothing is left in the stale map
     // the callers have synchronised every slot: no copy into h_seen is in flight
     std::lock_guard<std::mutex> lk(ctx->seen_mu);
     for (auto &sl : ctx->slots) memset(sl.h_seen, 0, kDiagWords * 4);

@@ -53,6 +53,7 @@ enum {
     kDiagInsertedWide = 4, // keys inserted into the wide table
     kDiagBadRow = 5,       // unused since ABI 3 (rows are validated in a pass of their own, see kRowFlag*)
     kDiagSpillRows = 6,    // rows in the spill log (DevWide::spill_n points here: one copy reads the whole fill state)
+    kDiagG1Drop = 7,       // TREW_FLAG_COMPAT_G1: the stale-row log or its carry was full (collect fails)
     kDiagWords = 16
 };
 
@@ -75,6 +76,22 @@ struct DevTable {
     u32 log2_part_slots;  // slots per partition = 1 << log2_part_slots; 512 partitions
     u32 *overflow;        // kDiagWords counters, see above
     const struct DevWide *wide;  // device-resident descriptor of the wide-entry table (k > 32)
+};
+
+// TREW_FLAG_COMPAT_G1 (pair mode): what the whole-read block of a pair recorded into temp_result_left stays there in the
+// reference's 64-bit branch and is added again by the next pair.  The exact kernel logs those rows and every pair's
+// chain flags; g1_apply_kernel adds them again after the batch's exact kernel, rows of the batch's last pair travel to the next
+// batch in a carry buffer.  Lives behind the DevTable in the context's device-resident descriptor (DevTableG1).
+struct DevG1 {
+    trew_hip_row *log;          // {k, table = forward_high | forward_low, word_lo, word_hi = pair index in the batch, count}
+    u32 *counters;              // [0] rows in log, [1] rows in the carry read by this batch, [2] rows in the carry it writes
+    unsigned char *pair_flags;  // per pair: bit b = all four segments chained for baseline b (kmer.cpp:378, 389);
+                                // bit 2 + b = the whole-read block's `both` condition (kmer.cpp:487, 494); zeroed per batch
+    u32 log_cap;
+};
+struct DevTableG1 {
+    DevTable t;
+    DevG1 g;
 };
 
 // wide entries (k in (32, 64], 128-bit words): tag / word halves / count per slot.  Kept behind a

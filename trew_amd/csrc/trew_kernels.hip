@@ -58,6 +58,7 @@ typedef unsigned __int128 u128;  // 2k-bit words for k in (32, 64] (k_mer_check_
 #include "kernels/driver_long.inc"
 #include "kernels/driver_pair.inc"
 #include "kernels/exact_kernel.inc"
+#include "kernels/g1_compat.inc"
 #include "kernels/table_kernels.inc"
 #include "kernels/synth_kernels.inc"
 
@@ -133,6 +134,14 @@ hipError_t fallback_counters_clear() {
 }
 
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_lds_bytes(cap, rawwords, wordbytes); }
+
+// TREW_FLAG_COMPAT_G1: behind the exact kernel of a pair batch, on the same stream (see kernels/g1_compat.inc)
+hipError_t launch_g1_apply(hipStream_t st, const DevTable &T, const DevG1 &G, const DevBatch &B, int min_mer, const trew_hip_row *carry_in,
+                           trew_hip_row *carry_out, u32 carry_cap) {
+    hipLaunchKernelGGL(g1_apply_kernel, dim3(256), dim3(256), 0, st, T, G, B, min_mer, carry_in, carry_out, carry_cap);
+    hipLaunchKernelGGL(g1_finish_kernel, dim3(1), dim3(1), 0, st, G);
+    return hipGetLastError();
+}
 
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable *T,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,

@@ -15,6 +15,8 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len, bool share);  // share: leave half of the wave slots to a prefilter on another stream
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes);
+hipError_t launch_g1_apply(hipStream_t st, const DevTable &T, const DevG1 &G, const DevBatch &B, int min_mer, const trew_hip_row *carry_in,
+                           trew_hip_row *carry_out, u32 carry_cap);
 hipError_t fallback_counters_read(u32 *out);  // kFallbackWords words of the current device
 hipError_t fallback_counters_clear();
 hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n, u32 *d_flags);
