@@ -158,3 +158,35 @@ def test_break_invariance_and_64_128_agreement():
         x = O.segment_check(O.OracleParams(max_mer=32), s[: n // 2], 5, min(n // 4, 32))
         y = O.segment_check(O.OracleParams(max_mer=64), s[: n // 2], 5, min(n // 4, 32))
         assert x == y
+
+
+def test_pair_compat_g1_is_the_cleared_result_plus_the_previous_pairs_whole_read_rows():
+    """compat_g1 (kmer.cpp:467-505 without the clear of 722-723): what a pair's whole-read block recorded is
+    added once more while the NEXT pair is processed.  With pairs whose only repeat is visible to the whole read alone
+    (period between n/4 and n/2) and a random mate, that second addition goes to `forward`: the tables are those of the
+    cleared semantics plus the forward rows of every pair but the last -- each obtained by running that pair on its own.
+    The survey's probe saw exactly this on 2 x 100 bp: forward 142 with `5 32`, 71 with `5 33`."""
+    import random
+
+    rnd = random.Random(11)
+
+    def rand(n):
+        return "".join(rnd.choice("ACGT") for _ in range(n))
+
+    r1, r2 = [], []
+    for i in range(12):
+        k = rnd.randint(26, 32)
+        r1.append(((rand(k) * 8)[:100] if i % 3 else rand(100)).encode())
+        r2.append(rand(100).encode())
+    cleared = O.run_pair(O.OracleParams(), r1, r2)
+    compat = O.run_pair(O.OracleParams(compat_g1=True), r1, r2)
+    want = {t: dict(v) for t, v in cleared.items()}
+    for a, b in list(zip(r1, r2))[:-1]:
+        own = O.run_pair(O.OracleParams(), [a], [b])
+        for t in ("forward_high", "forward_low"):
+            for key, cnt in own[t].items():
+                want[t][key] = want[t].get(key, 0) + cnt
+    assert compat == want and compat != cleared
+    assert sum(compat["forward_high"].values()) > 1.8 * sum(cleared["forward_high"].values()) - 80
+    # MAX_MER > 32: the 128-bit branch clears the map, the switch changes nothing
+    assert O.run_pair(O.OracleParams(max_mer=33, compat_g1=True), r1, r2) == O.run_pair(O.OracleParams(max_mer=33), r1, r2)
