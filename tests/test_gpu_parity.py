@@ -843,6 +843,40 @@ def test_repeated_passes_are_identical():
         t.free(d)
 
 
+@pytest.mark.parametrize("mode", ["short", "pair"])
+def test_overlapping_batches_share_the_chip_and_agree(mode):
+    """Batches queued on two slots without a wait in between: an exact kernel that finds the other slot busy takes half of
+    its wave slots so that the other batch's prefilter is resident beside it (launch_exact, `share`), and the two kernels pull
+    from their queues at speeds that differ from pass to pass.  Every pass must give the tables of the same parts run one at
+    a time on one slot (tools/stress_overlap.py is the long version: 60 passes of 8 M reads, 30 of 4 M pairs)."""
+    L, seed, parts = 150, 20250218, 8
+    pair = mode == "pair"
+    rp = 2 if pair else 1
+    per = 250_000 if pair else 500_000
+    stride = 3 * ((L + 31) // 32)
+    with T.TrewHip(mode=T.MODE_PAIR if pair else T.MODE_SHORT, n_slots=2, max_batch_reads=rp * per, max_batch_words=16, table_log2_slots=20) as t:
+        bufs = []
+        for p in range(parts):
+            d = t.malloc(rp * per * stride * 4 + 64)
+            (t.synth_pair_device if pair else t.synth_short_device)(seed, p * per, per, L, d)
+            bufs.append(d)
+        for d in bufs:
+            t.submit(t.device_uniform_batch(d, rp * per, L), 0)
+            t.wait(0)
+        ref = t.collect()
+        assert sum(len(v) for v in ref.values()) > 1000
+        for rep in range(8):
+            t.reset_tables()
+            for i, d in enumerate(bufs):
+                t.submit(t.device_uniform_batch(d, rp * per, L), (i + rep) & 1)
+            t.wait(0)
+            t.wait(1)
+            got = t.collect()
+            assert got == ref, (rep, _table_diff(got, ref))
+        for d in bufs:
+            t.free(d)
+
+
 def test_full_size_config3_pairs():
     """BASELINE config 3 at full size (50 M pairs of 2 x 150 bp, device-generated, 6 GB of packed reads):
     sharding invariance of the tables, and bit-exactness against the CPU oracle on a 30 k-pair prefix
