@@ -728,18 +728,34 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
 struct PairJob {
     LineIndex index[2];
     std::atomic<size_t> next_block{0}, next_item{0};
-    size_t n_pairs = 0, pairs_per_item = 1 << 16;
+    size_t n_pairs = 0, pairs_per_item = 1 << 16;  // run_pair_blocks picks the item size (text batches: small items, see pair_worker_loop)
 };
+
+// page-table entries of [lo, hi) of a mapped file: in with one call instead of a fault per 64 KiB (before the first pass), out
+// again once a worker is done with the range (one munmap of both files at the end is single-threaded: 0.1 s for 10 GB)
+static void map_range(const LineIndex &ix, size_t lo, size_t hi, bool in) {
+    const size_t page = 4096;
+    hi = std::min(hi, ix.size);
+    if (in) {
+#ifdef MADV_POPULATE_READ
+        const size_t plo = lo & ~(page - 1);
+        if (hi > plo) (void) madvise(const_cast<char *>(ix.base) + plo, hi - plo, MADV_POPULATE_READ);
+#endif
+    } else {
+        const size_t plo = (lo + page - 1) & ~(page - 1), phi = hi & ~(page - 1);
+        if (phi > plo) (void) madvise(const_cast<char *>(ix.base) + plo, phi - plo, MADV_DONTNEED);
+    }
+}
 
 static void pair_count_loop(PairJob *job) {
     const size_t n0 = job->index[0].n_blocks, total = n0 + job->index[1].n_blocks;
     for (;;) {
         const size_t i = job->next_block.fetch_add(1);
         if (i >= total) break;
-        if (i < n0)
-            job->index[0].count_block(i);
-        else
-            job->index[1].count_block(i - n0);
+        LineIndex &ix = job->index[i < n0 ? 0 : 1];
+        const size_t b = i < n0 ? i : i - n0;
+        map_range(ix, b * ix.block, (b + 1) * ix.block, true);
+        ix.count_block(b);
     }
 }
 
@@ -749,17 +765,68 @@ static void pair_worker_loop(Scanner *s, Worker *w, PairJob *job) {
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     LineCursor cur[2];
     std::vector<int64_t> st[2], nd[2];
+    // Text batches (default): the sequence bytes of both mates, interleaved, accumulate over several work items until a
+    // batch is full; the device packs (as block_worker_loop).  An item is small enough (pairs_per_item) for the copy to find
+    // the lines that the cursor has just scanned still in cache.
+    const bool text = !s->cfg.host_pack;
+    unsigned char *h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
+    const uint64_t bytes_cap = w->text_cap - 12ull * w->reads_cap;
+    uint64_t acc_reads = 0, acc_words = 0, acc_bytes = 0;
+    bool same_len = true, buffers_free = false;
+    uint32_t first_len = 0;
+    if (text && w->tmp_off.size() < w->reads_cap) {
+        w->tmp_off.resize(w->reads_cap);
+        w->tmp_len.resize(w->reads_cap);
+        w->tmp_woff.resize(w->reads_cap);
+    }
+    auto close_text_batch = [&]() {
+        if (acc_reads == 0) return;
+        const clk::time_point t3 = clk::now();
+        trew_hip_ascii_batch b;
+        memset(&b, 0, sizeof(b));
+        b.bases = (const char *) h_bases;
+        b.n_bytes = acc_bytes;
+        b.n_reads = acc_reads;
+        if (same_len && first_len > 0) {
+            b.uniform_length = first_len;
+        } else {
+            uint32_t *arr = (uint32_t *) (h_bases - 12ull * acc_reads);
+            memcpy(arr, w->tmp_woff.data(), acc_reads * 4);
+            memcpy(arr + acc_reads, w->tmp_off.data(), acc_reads * 4);
+            memcpy(arr + 2 * acc_reads, w->tmp_len.data(), acc_reads * 4);
+            b.word_offsets = arr;
+            b.byte_offsets = arr + acc_reads;
+            b.lengths = arr + 2 * acc_reads;
+        }
+        submit_text(s, w, b, acc_bytes);
+        acc_reads = acc_words = acc_bytes = 0;
+        same_len = true;
+        std::swap(w->slot, w->slot_b);  // two slots, two pinned buffers: fill the next batch while this one travels
+        std::swap(w->h_buf, w->h_buf_b);
+        h_bases = (unsigned char *) w->h_buf + 12ull * w->reads_cap;
+        buffers_free = false;
+        w->t_submit += secs(t3, clk::now());
+    };
     for (;;) {
         const size_t item = job->next_item.fetch_add(1);
         const size_t r0 = item * job->pairs_per_item;
         if (r0 >= job->n_pairs) break;
         const size_t r1 = std::min(job->n_pairs, r0 + job->pairs_per_item);
+        const clk::time_point tc = clk::now();
+        for (int m = 0; m < 2; m++) cur[m].init(job->index[m].base, job->index[m].size, job->index[m].line_start((int64_t) (4 * r0), w->nl));
+        w->t_scan += secs(tc, clk::now());
+        int64_t first_byte[2] = {-1, -1}, last_byte[2] = {-1, -1};
+        // text batches: the item is walked in pieces small enough for the copy to find the lines just scanned in cache (the
+        // cursors carry on from piece to piece; locating a line from the block counts costs a scan of its 4 MiB block)
+        const size_t piece = text ? (size_t) 8192 : job->pairs_per_item;
+        for (size_t q0 = r0; q0 < r1; q0 += piece) {
+        const size_t q1 = std::min(r1, q0 + piece);
         const clk::time_point t0 = clk::now();
+        uint64_t need_words = 0, need_bytes = 0;
         for (int m = 0; m < 2; m++) {
-            cur[m].init(job->index[m].base, job->index[m].size, job->index[m].line_start((int64_t) (4 * r0), w->nl));
             st[m].clear();
             nd[m].clear();
-            for (size_t r = r0; r < r1; r++) {
+            for (size_t r = q0; r < q1; r++) {
                 const int64_t a = cur[m].next(), b = cur[m].next(), x = cur[m].next(), y = cur[m].next();
                 if (a < 0 || b < 0) die("internal error: the paired reader ran past the end of a file");
                 (void) x;
@@ -768,37 +835,87 @@ static void pair_worker_loop(Scanner *s, Worker *w, PairJob *job) {
                     die("This mode is designed for short-read sequencing. Please use 'trew long'.");
                 st[m].push_back(a + 1);
                 nd[m].push_back(b - 1);
+                const uint64_t len = (uint64_t) std::max<int64_t>(0, b - a - 1);
+                need_words += 3ull * ((len + 31) / 32);
+                need_bytes += len;
+            }
+            if (!st[m].empty()) {
+                if (first_byte[m] < 0) first_byte[m] = st[m].front();
+                last_byte[m] = nd[m].back();
             }
         }
         const clk::time_point t1 = clk::now();
         w->t_scan += secs(t0, t1);
-        // as many pairs per batch as the slot's buffers hold
-        for (size_t at = 0; at < st[0].size();) {
-            size_t n = 0;
-            uint64_t words = 0;
-            while (at + n < st[0].size() && 2 * (n + 1) <= w->reads_cap) {
-                const uint64_t need = 3ull * (((uint64_t) (nd[0][at + n] - st[0][at + n] + 1) + 31) / 32) + 3ull * (((uint64_t) (nd[1][at + n] - st[1][at + n] + 1) + 31) / 32);
-                if (words + need > w->words_cap) break;
-                words += need;
-                n++;
+        if (text) {
+            const uint64_t item_reads = 2 * (uint64_t) st[0].size();
+            if (acc_reads + item_reads > w->reads_cap || acc_words + need_words > w->words_cap || acc_bytes + need_bytes > bytes_cap) close_text_batch();
+            if (item_reads > w->reads_cap || need_words > w->words_cap || need_bytes > bytes_cap) die("internal error: one item's pairs do not fit the slot buffer");
+            if (!buffers_free) {
+                const clk::time_point tw = clk::now();
+                if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
+                buffers_free = true;
+                w->t_wait += secs(tw, clk::now());
             }
-            if (n == 0) die("internal error: a pair does not fit the slot buffer");  // MAX_SEQ bounds a pair far below words_cap; never spin
-            const clk::time_point tw = clk::now();
-            if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
             const clk::time_point t2 = clk::now();
-            const uint64_t n_reads = 2 * n;
-            const uint64_t nw = trew_pack_pairs(job->index[0].base, st[0].data() + at, nd[0].data() + at, job->index[1].base, st[1].data() + at, nd[1].data() + at, n,
-                                                w->h_buf + 2 * n_reads, w->words_cap, w->h_buf, w->h_buf + n_reads);
-            const clk::time_point t3 = clk::now();
-            submit_packed(s, w, w->h_buf + 2 * n_reads, w->h_buf, w->h_buf + n_reads, n_reads, nw);
-            w->t_wait += secs(tw, t2);
-            w->t_pack += secs(t2, t3);
-            w->t_submit += secs(t3, clk::now());
-            at += n;
-            std::swap(w->slot, w->slot_b);  // two slots, two pinned buffers: pack the next batch while this one travels
-            std::swap(w->h_buf, w->h_buf_b);
+            if (acc_reads == 0 && !st[0].empty()) first_len = (uint32_t) std::max<int64_t>(0, nd[0][0] - st[0][0] + 1);
+            uint64_t wo = acc_words, bo = acc_bytes, rr = acc_reads;
+            const int64_t safe_src[2] = {(int64_t) job->index[0].size - 288, (int64_t) job->index[1].size - 288};
+            for (size_t i = 0; i < st[0].size(); i++) {
+                for (int m = 0; m < 2; m++) {
+                    const int64_t a = st[m][i], len64 = nd[m][i] - a + 1;
+                    const uint32_t len = len64 > 0 ? (uint32_t) len64 : 0u;
+                    if (len <= 256 && a <= safe_src[m])
+                        copy_short_line(h_bases + bo, job->index[m].base + a, len);
+                    else
+                        memcpy(h_bases + bo, job->index[m].base + a, len);
+                    w->tmp_woff[rr] = (uint32_t) wo;
+                    w->tmp_off[rr] = (uint32_t) bo;
+                    w->tmp_len[rr] = len;
+                    rr++;
+                    same_len = same_len && len == first_len;
+                    wo += 3ull * (((uint64_t) len + 31) / 32);
+                    bo += len;
+                }
+            }
+            acc_words = wo;
+            acc_bytes = bo;
+            acc_reads = rr;
+            w->t_pack += secs(t2, clk::now());
+            if (acc_bytes >= ((uint64_t) s->cfg.batch_mib << 19)) close_text_batch();  // batch_mib of FASTQ text is about half as many sequence bytes
+        } else {
+            // as many pairs per batch as the slot's buffers hold
+            for (size_t at = 0; at < st[0].size();) {
+                size_t n = 0;
+                uint64_t words = 0;
+                while (at + n < st[0].size() && 2 * (n + 1) <= w->reads_cap) {
+                    const uint64_t need = 3ull * (((uint64_t) (nd[0][at + n] - st[0][at + n] + 1) + 31) / 32) + 3ull * (((uint64_t) (nd[1][at + n] - st[1][at + n] + 1) + 31) / 32);
+                    if (words + need > w->words_cap) break;
+                    words += need;
+                    n++;
+                }
+                if (n == 0) die("internal error: a pair does not fit the slot buffer");  // MAX_SEQ bounds a pair far below words_cap; never spin
+                const clk::time_point tw = clk::now();
+                if (trew_hip_wait(c, w->slot)) hip_die(c, "trew_hip_wait");  // the slot's pinned buffer is free again
+                const clk::time_point t2 = clk::now();
+                const uint64_t n_reads = 2 * n;
+                const uint64_t nw = trew_pack_pairs(job->index[0].base, st[0].data() + at, nd[0].data() + at, job->index[1].base, st[1].data() + at, nd[1].data() + at, n,
+                                                    w->h_buf + 2 * n_reads, w->words_cap, w->h_buf, w->h_buf + n_reads);
+                const clk::time_point t3 = clk::now();
+                submit_packed(s, w, w->h_buf + 2 * n_reads, w->h_buf, w->h_buf + n_reads, n_reads, nw);
+                w->t_wait += secs(tw, t2);
+                w->t_pack += secs(t2, t3);
+                w->t_submit += secs(t3, clk::now());
+                at += n;
+                std::swap(w->slot, w->slot_b);  // two slots, two pinned buffers: pack the next batch while this one travels
+                std::swap(w->h_buf, w->h_buf_b);
+            }
         }
+        }  // pieces
+        // the item's bytes are in pinned buffers: give the page-table entries of its stretch of both files back
+        for (int m = 0; m < 2; m++)
+            if (first_byte[m] >= 0) map_range(job->index[m], (size_t) first_byte[m], (size_t) last_byte[m], false);
     }
+    if (text) close_text_batch();
     if (trew_hip_wait(c, w->slot) || trew_hip_wait(c, w->slot_b)) hip_die(c, "trew_hip_wait");
 }
 
@@ -828,29 +945,41 @@ struct Mapping {
 
 // false when a file cannot be mapped: the caller falls back to the serial reader
 static bool run_pair_blocks(Scanner *s, const char *name1, const char *name2) {
-    Mapping m1, m2;
-    if (!m1.map(name1) || !m2.map(name2)) return false;
-    PairJob job;
-    job.index[0].init((const char *) m1.p, m1.size, (size_t) LENGTH);
-    job.index[1].init((const char *) m2.p, m2.size, (size_t) LENGTH);
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
     {
+        Mapping m1, m2;
+        if (!m1.map(name1) || !m2.map(name2)) return false;
+        PairJob job;
+        job.index[0].init((const char *) m1.p, m1.size, (size_t) LENGTH);
+        job.index[1].init((const char *) m2.p, m2.size, (size_t) LENGTH);
+        {
+            std::vector<std::thread> th;
+            for (size_t i = 0; i < s->workers.size(); i++) th.emplace_back(pair_count_loop, &job);
+            for (auto &t : th) t.join();
+        }
+        job.index[0].finish();
+        job.index[1].finish();
+        const long long num1 = job.index[0].total(), num2 = job.index[1].total();
+        if (num1 != num2) {  // kmer.cpp:1112-1114
+            fprintf(stderr, "Error: Mismatched record counts between files (num1: %lld, num2: %lld).\n", num1, num2);
+            fflush(stdout);
+            fflush(stderr);
+            _exit(EXIT_FAILURE);
+        }
+        job.n_pairs = (size_t) ((num1 + 2) / 4);  // sequence lines closed by a newline: line numbers 1, 5, 9, ...
+        if (const char *e = getenv("TREW_PAIR_ITEM")) job.pairs_per_item = (size_t) std::max(1L, atol(e));  // experiments
+        const clk::time_point t1 = clk::now();
         std::vector<std::thread> th;
-        for (size_t i = 0; i < s->workers.size(); i++) th.emplace_back(pair_count_loop, &job);
+        for (auto &w : s->workers) th.emplace_back(pair_worker_loop, s, &w, &job);
         for (auto &t : th) t.join();
+        const clk::time_point t2 = clk::now();
+        s->t_map = secs(t0, t1);  // mapping + the counting pass over both files
+        s->t_workers = secs(t1, t2);
+        s->t_unmap = -secs(t0, t2);  // completed below, once the mappings are gone
     }
-    job.index[0].finish();
-    job.index[1].finish();
-    const long long num1 = job.index[0].total(), num2 = job.index[1].total();
-    if (num1 != num2) {  // kmer.cpp:1112-1114
-        fprintf(stderr, "Error: Mismatched record counts between files (num1: %lld, num2: %lld).\n", num1, num2);
-        fflush(stdout);
-        fflush(stderr);
-        _exit(EXIT_FAILURE);
-    }
-    job.n_pairs = (size_t) ((num1 + 2) / 4);  // sequence lines closed by a newline: line numbers 1, 5, 9, ...
-    std::vector<std::thread> th;
-    for (auto &w : s->workers) th.emplace_back(pair_worker_loop, s, &w, &job);
-    for (auto &t : th) t.join();
+    s->t_unmap += secs(t0, clk::now());
     return true;
 }
 
