@@ -586,7 +586,10 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
     trew_hip_ctx *c = s->dev[(size_t) w->dev_index]->ctx;
     typedef std::chrono::steady_clock clk;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    const bool text = !s->cfg.host_pack;  // ship the sequence bytes, the device applies codes[] (pack kernel); else trew_pack_reads here
+    // ship the sequence bytes, the device applies codes[] (pack kernel); else trew_pack_reads here.  Long reads are packed on the
+    // host: their kernels take longer per base and a byte per base over PCIe (against 3 bits) then makes the workers wait for
+    // their slots -- 29.0 against 30.7 Gbases/s on 300 k ONT-like reads (tools/e2e_long.py, profiles/r03/README.md)
+    const bool text = !s->cfg.host_pack && !job->long_mode;
 #if defined(__x86_64__)
     const bool inline_copy = __builtin_cpu_supports("avx2") && !getenv("TREW_AB_MEMCPY");
 #else
