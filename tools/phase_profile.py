@@ -37,6 +37,8 @@ a, e, fl = t.last_timing(0)
 print("filter %.4f ms exact %.4f ms flagged %d" % (a, e, fl))
 for i, nm in enumerate(names):
     print("%-12s %14d  %5.1f %%" % (nm, out[i], 100.0 * out[i] / tot))
+if mode == "long":
+    print("long walks: max steps per read %d; reads with <=4 / <=16 / <=64 / <=128 / <=256 / more steps: %s; steps in all %d" % (out[24], [int(out[i]) for i in range(25, 31)], out[31]))
 cn = ["reads", "runs_calls", "windows_calls", "records", "runs_total", "k5_calls"]
 for i, nm in enumerate(cn):
     print("%-14s %10d" % (nm, out[16 + i]))
