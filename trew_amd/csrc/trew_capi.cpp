@@ -31,7 +31,7 @@ struct Slot {
     unsigned char *d_ascii = nullptr;  // text batches: [word_offsets][byte_offsets][lengths][bases], max_batch_ascii_bytes + slack
     u32 *d_wl = nullptr;
     u32 *d_wl_count = nullptr;
-    int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kMaxSlots * kThrRow)
+    int2 *d_thr = nullptr;   // pass thresholds of the prefilter's uniform-geometry path (kThrRows * kThrRow)
     int2 *h_thr = nullptr;   // pinned staging of the same
     hipEvent_t ev_tail = nullptr, ev_copied = nullptr;  // order the context's copy stream behind / in front of this slot's stream (BatchCopy)
     u32 *h_seen = nullptr;   // TREW_FLAG_TRACK_PRESSURE: the counter line as of the end of this slot's last batch (pinned, behind h_thr)
@@ -286,9 +286,9 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMalloc((void **) &s.d_ascii, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMalloc(text buffer)", e);
             if ((e = hipMemset(s.d_ascii, 0, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMemset", e);
         }
-        if ((e = hipMalloc((void **) &s.d_thr, kMaxSlots * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
-        if ((e = hipHostMalloc((void **) &s.h_thr, kMaxSlots * kThrRow * sizeof(int2) + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
-        s.h_seen = (u32 *) (s.h_thr + kMaxSlots * kThrRow);
+        if ((e = hipMalloc((void **) &s.d_thr, kThrRows * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
+        if ((e = hipHostMalloc((void **) &s.h_thr, kThrRows * kThrRow * sizeof(int2) + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
+        s.h_seen = (u32 *) (s.h_thr + kThrRows * kThrRow);
         memset(s.h_seen, 0, kDiagWords * 4);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
@@ -305,6 +305,10 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             for (int j = 0; j < 3; j++)
                 if ((e = hipEventCreate(&s.ev[i][j])) != hipSuccess) return bail("hipEventCreate", e);
     }
+    // hipMemset is queued on the null stream and may return before it has run; the slots' streams are non-blocking (they do not
+    // wait for the null stream), so a first batch submitted right away could have its worklist counters or table rows wiped
+    // by a memset that was still pending -- seen once in four hundred fuzz seeds as a context that returned empty tables
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail("hipDeviceSynchronize", e);
     *out = ctx;
     return 0;
 }
@@ -532,7 +536,7 @@ static int stage_thresholds(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, cons
     if (s.thr_length != db.uniform_length) {
         HIPCHK(ctx, hipStreamSynchronize(s.stream));  // an earlier copy may still be reading the staging buffer
         fill_thresholds(ctx->dp, db.uniform_length, s.h_thr);
-        HIPCHK(ctx, hipMemcpyAsync(s.d_thr, s.h_thr, kMaxSlots * kThrRow * sizeof(int2), hipMemcpyHostToDevice, s.stream));
+        HIPCHK(ctx, hipMemcpyAsync(s.d_thr, s.h_thr, kThrRows * kThrRow * sizeof(int2), hipMemcpyHostToDevice, s.stream));
         s.thr_length = db.uniform_length;
     }
     *out = s.d_thr;
@@ -867,6 +871,7 @@ static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
     HIPCHK(ctx, fallback_counters_clear());
     if (ctx->g1.counters) HIPCHK(ctx, hipMemset(ctx->g1.counters, 0, 16));  // a new input: nothing is left in the stale map
+    HIPCHK(ctx, hipStreamSynchronize(nullptr));  // the memsets above are null-stream work that the slots' non-blocking streams do not wait for
     // the callers have synchronised every slot: no copy into h_seen is in flight
     std::lock_guard<std::mutex> lk(ctx->seen_mu);
     for (auto &sl : ctx->slots) memset(sl.h_seen, 0, kDiagWords * 4);

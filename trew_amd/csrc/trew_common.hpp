@@ -18,6 +18,7 @@ typedef uint64_t u64;
 constexpr int kMaxSlots = 6;        // segments per unit: short 3, pair 6, long 2, segment 1
 constexpr int kMaxSegBases = 1023;  // longest segment any kernel accepts (short mode rejects reads > 1000, kmer.cpp:1006-1009)
 constexpr int kTablePartBits = 9;   // low word bits that select the table partition (see table_add)
+constexpr int kThrRows = kMaxSlots + 2;  // rows of the threshold table: one per slot + one per pair of halves of unequal length (joint rows, fill_thresholds)
 constexpr int kThrRow = 66;         // threshold-table entries per slot: k = 1..64, one of read-ahead padding, one to keep rows 16-byte aligned
 
 struct DevParams {

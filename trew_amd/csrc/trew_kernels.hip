@@ -97,6 +97,30 @@ void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
             table[slot * kThrRow + k - 1] = th;
         }
     }
+    // Joint rows (row kMaxSlots + p for the halves 2p, 2p + 1 of a read of odd length, where the right half is one base longer
+    // than the left): the prefilter judges both halves in ONE k loop with the left half's geometry -- the right half by its
+    // first len_A bases, B'.  The windows of B' are the first W_A of B's W_B = W_A + 1 windows, so a class with ithr_B of B's
+    // windows has at least ithr_B - (W_B - Weff) among the Weff windows the kernel looks at; one threshold serves both halves:
+    // the smaller of the two (the right half's), which keeps the filter sound and costs the left half at most one count.
+    for (int p = 0; p < 2; p++) {
+        const Segment a = get_segment(P.mode, 2 * p, uniform_length, uniform_length, P.min_mer, P.max_mer, P.slice_len);
+        const Segment b = get_segment(P.mode, 2 * p + 1, uniform_length, uniform_length, P.min_mer, P.max_mer, P.slice_len);
+        const bool ok = 2 * p + 1 < nslots && a.valid && b.valid && b.len == a.len + 1;
+        for (int k = 1; k <= kThrRow; k++) {
+            int2 th;
+            th.x = 0x7fffffff;
+            th.y = -1;
+            const int WA = (int) a.len - k + 1, WB = WA + 1;
+            if (ok && WA > 0) {
+                const int Weff = uni_windows(nw, (int) a.len, k);
+                const volatile float pa = (float) WA * P.lowf, pb = (float) WB * P.lowf;
+                const int xa = (int) floorf(pa) + 1 - (WA - Weff), xb = (int) floorf(pb) + 1 - (WB - Weff);
+                th.x = std::min(xa, xb);
+                th.y = Weff - th.x;
+            }
+            table[(kMaxSlots + p) * kThrRow + k - 1] = th;
+        }
+    }
 }
 
 hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevParams &P, const DevBatch &B, u32 *wl, u32 *wl_count,
