@@ -64,7 +64,7 @@ struct trew_hip_ctx {
     trew_hip_params p;
     DevParams dp;
     DevTable table;
-    DevTable *d_table = nullptr;  // device copy of `table` (a DevTableG1) for the exact kernels, which take it by pointer (exact_core.inc, TableRef)
+    DevTableG1 table_g1;  // `table` (with TREW_FLAG_DEBUG_NO_EMIT applied) + g1: the exact kernels' descriptor argument
     // TREW_FLAG_COMPAT_G1 (kernels/g1_compat.inc): the stale-row log, the pair flags and the two carry buffers (read / written
     // by a batch, swapped after it)
     DevG1 g1 = {nullptr, nullptr, nullptr, 0};
@@ -261,8 +261,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         tbl.t = ctx->table;
         tbl.g = ctx->g1;
         if (p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.t.log2_part_slots = 0xffffffffu;  // cached_add drops every row
-        if ((e = hipMalloc((void **) &ctx->d_table, sizeof(DevTableG1))) != hipSuccess) return bail("hipMalloc(table descriptor)", e);
-        if ((e = hipMemcpy(ctx->d_table, &tbl, sizeof(DevTableG1), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+        ctx->table_g1 = tbl;
     }
 
     if ((e = hipMalloc((void **) &ctx->d_row_flags, kRowFlagWords * 4)) != hipSuccess) return bail("hipMalloc(row flags)", e);
@@ -347,7 +346,6 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
     if (ctx->wide.wcount) (void) hipFree(ctx->wide.wcount);
     if (ctx->wide.spill_rows) (void) hipFree(ctx->wide.spill_rows);
     if (ctx->table.wide) (void) hipFree((void *) ctx->table.wide);
-    if (ctx->d_table) (void) hipFree(ctx->d_table);
     if (ctx->g1.log) (void) hipFree(ctx->g1.log);
     if (ctx->g1.counters) (void) hipFree(ctx->g1.counters);
     if (ctx->g1.pair_flags) (void) hipFree(ctx->g1.pair_flags);
@@ -600,7 +598,7 @@ static int launch_batch(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, u32 max_
         share = hipStreamQuery(ctx->slots[(size_t) prev].stream) == hipErrorNotReady;
         (void) hipGetLastError();
     }
-    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->d_table, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg, share));
+    SUBMIT_CHK(launch_exact(s.stream, (u32) ctx->n_cu, db.n_units, ctx->dp, db, ctx->table_g1, s.d_wl, wl_count, wl_count_next, wl_cap, s.res, cap, rawwords, max_seg, share));
     if (timed) SUBMIT_CHK(hipEventRecord(ev[2], s.stream));
     if (compat_g1) {  // the stale rows of this batch's pairs (and of the previous batch's tail) are added again, in file order
         SUBMIT_CHK(launch_g1_apply(s.stream, ctx->table, ctx->g1, db, ctx->dp.min_mer, ctx->g1_carry[ctx->g1_batches & 1], ctx->g1_carry[(ctx->g1_batches + 1) & 1],

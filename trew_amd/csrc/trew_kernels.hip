@@ -167,7 +167,7 @@ hipError_t launch_g1_apply(hipStream_t st, const DevTable &T, const DevG1 &G, co
     return hipGetLastError();
 }
 
-hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTable *T,
+hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTableG1 &T,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len, bool share) {
     // lane_bounds needs every staged segment (< cap) to fit its NW words
@@ -180,7 +180,7 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     const u32 bound_len = P.mode == TREW_MODE_LONG ? (u32) P.slice_len : max_seg_len;
     const int nw = (P.flags & TREW_FLAG_NO_FILTER) ? 0 : (bound_len <= 95 ? 3 : bound_len <= 159 ? 5 : bound_len <= 319 ? 10 : 0);
     // one block = one wave; fill the chip exactly once (persistent, self-scheduling waves)
-    typedef void (*kern_t)(DevParams, DevBatch, const DevTable *, const u32 *, u32 *, u32 *, u32, SegResults, u32, u32);
+    typedef void (*kern_t)(DevParams, DevBatch, DevTableG1, const u32 *, u32 *, u32 *, u32, SegResults, u32, u32);
     kern_t fn = nullptr;
 #define TREW_PICK_MODE(NWV, WTV)                                                      \
     switch (P.mode) {                                                                 \
