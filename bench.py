@@ -220,7 +220,9 @@ def timed_run(w, args, steps, warmup, world, barrier, reduce_fn):
         t.wait(s)
     host_ms = (time.perf_counter() - t0) * 1e3 / steps
     rows = t.collect_rows() if world == 1 else None
-    merged = reduce_fn(t, rows)
+    t1 = time.perf_counter()
+    merged = reduce_fn(t, rows)  # N > 1: the table exchange, inside the timed region
+    exchange_ms = (time.perf_counter() - t1) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     # mean HIP-event durations of the timed passes, on the kernels' own streams
@@ -229,7 +231,7 @@ def timed_run(w, args, steps, warmup, world, barrier, reduce_fn):
         k = len(range(s, steps, nslots))
         a, b, nf = t.last_timing(s)
         fs, es, cnt, nflag = fs + a * k, es + b * k, cnt + k, nf
-    return {"dt": dt, "host_ms": host_ms, "filter_ms": fs / cnt, "exact_ms": es / cnt, "serial_ms": serial, "nflag": int(nflag), "rows": merged}
+    return {"dt": dt, "host_ms": host_ms, "filter_ms": fs / cnt, "exact_ms": es / cnt, "serial_ms": serial, "nflag": int(nflag), "rows": merged, "exchange_ms": exchange_ms}
 
 
 def oracle_check(w, args, O, cores):
@@ -326,6 +328,47 @@ def end_to_end(capi, args, cores):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def launch_ranks(n):
+    """Start `n` ranks of this very command under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) as a
+    child process, relay its output, return its exit status.  Nothing here imports torch or touches the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_launch(args):
+    """--rehearse-launch: the ranks meet, agree on the world size and leave; no GPU, no scan (see the option's help)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        seen = int(t.item())
+        dist.destroy_process_group()
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "value": None,
+                          "note": "launch rehearsal only: the ranks were started and counted, nothing was scanned"}))
+        sys.stdout.flush()
+    return 0 if seen == args.gpus else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,7 +395,21 @@ def main():
     ap.add_argument("--exchange", default="auto", choices=["auto", "device", "host"],
                     help="table reduction: device = collect_device -> all_gather of device tensors -> add_rows_device (what nccl runs use); "
                          "host = the same exchange with host-side row arrays; auto = device with nccl, host otherwise")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="test aid (no GPU needed): every rank joins the process group, the ranks agree on the world size with one all_reduce, "
+                         "rank 0 prints {n_gpus, rehearsal: true} and nothing is scanned -- exercises the self-launch of --gpus N on a CPU box")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started plainly: start the N ranks ourselves, BEFORE torch or HIP is imported or any GPU call is
+    # made in this process (a process that has touched the GPU must not be replaced or forked into ranks).  The children run
+    # under torch.distributed.run exactly as the driver would start them; rank 0's JSON line is relayed, the exit status is theirs.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to run a job of another size than the one asked for" % (args.gpus, world_env))
+    if args.rehearse_launch:
+        sys.exit(rehearse_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -380,9 +437,6 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     dev = torch.device("cuda", dev_index)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-
     L = args.read_len
     default_reads = {"short": 10_000_000 if world == 1 else CONFIG5_READS_PER_GPU, "pair": 50_000_000, "long": 1_000_000}
     n = args.reads or default_reads[args.mode]
@@ -484,6 +538,9 @@ def main():
             "host_ms_per_step": round(m["host_ms"], 4),
             "table_rows": int(len(m["rows"])) if m["rows"] is not None else None,
         }
+        if world > 1:
+            # rank 0's wall time of the one exchange of the job (compaction -> all_gather -> merge kernel -> final rows), part of dt
+            out["exchange_ms"] = round(m["exchange_ms"], 3)
 
     # CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1 only)
     do_cpu = rank == 0 and world == 1 and not args.no_cpu

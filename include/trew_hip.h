@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define TREW_HIP_ABI_VERSION 3
+#define TREW_HIP_ABI_VERSION 4
 
 /* scan modes: which per-read driver of the reference is reproduced */
 enum {
@@ -65,6 +65,8 @@ enum {
                                 if that pair's four segments chain, else to `forward` (kmer.cpp:378-399, 438-455).  Batches must
                                 be submitted in file order; this reproduces the reference run with ONE consumer thread (with
                                 more its output depends on scheduling).  Default: the cleared semantics. */
+    TREW_FLAG_DEBUG_NO_GROUP = 1024, /* tests and A/B runs: the exact kernel gives every segment a wave of its own (decide()) instead
+                                of deciding four segments in lock step, 16 lanes each (decide_group); results are identical */
     TREW_FLAG_TRACK_PRESSURE = 256 /* every batch ends with a copy of the table's fill counters into pinned host memory, and
                                 trew_hip_table_pressure answers from those copies (and from what collect / add_rows /
                                 reset read since) instead of asking the device: for hosts that ask before every batch.
@@ -198,6 +200,15 @@ int trew_hip_merge(trew_hip_ctx *dst, trew_hip_ctx *src);
  * larger slices.  Matches the thread merge of process_output, kmer.cpp:1486-1515 (sums over contributors). */
 int trew_hip_add_gathered_device(trew_hip_ctx *ctx, const trew_hip_row *d_buf, uint32_t n_slices, uint32_t own_slice,
                                  uint64_t slice_rows, void *producer_stream, uint64_t *max_rows);
+/* The producing side of that exchange with no host hop (ABI 4): compacts the context's tables straight into rows 1.. of
+ * d_slice (1 + slice_rows rows of device memory) and writes the header row -- count = rows the rank has, which may
+ * exceed slice_rows (then only slice_rows of them are there and trew_hip_add_gathered_device reports it on every rank) --
+ * with a kernel of its own behind the compaction; the spill log is appended on the device as well.  consumer_stream:
+ * the HIP stream the collective will be issued on; it is made to wait for the header on the device (and this call first
+ * waits, on the device, for what that stream still has queued on the slice), so the host neither reads the count nor
+ * writes the header.  NULL = synchronise the device before and after instead.  n_rows may be NULL; asking for the count
+ * costs one host synchronisation.  Replaces the size exchange a merge of per-thread maps needs (kmer.cpp:1486-1515). */
+int trew_hip_collect_slice_device(trew_hip_ctx *ctx, trew_hip_row *d_slice, uint64_t slice_rows, void *consumer_stream, uint64_t *n_rows);
 
 /* Fill state of the device tables (a snapshot; does not wait for running batches).  The reference's hash maps
  * grow without bound (absl::flat_hash_map, kmer.h:79); the device table has a fixed number of slots, rows that
@@ -214,8 +225,10 @@ int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *t
  * out[0] decide(): speculative skip refused, segment decided again with every k counted
  * out[1] eval_runs(): more than 64 runs of adjacent same-class windows, classes counted window by window
  * out[2] wide table (k > 32): gave up waiting for a slot's ready bit (collect merges the duplicate slot this can leave)
- * out[3] keys inserted into the narrow table, out[4] into the wide table.   n <= TREW_DEBUG_COUNTERS entries are written. */
-#define TREW_DEBUG_COUNTERS 5
+ * out[3] keys inserted into the narrow table, out[4] into the wide table
+ * out[5] decide_group(): a 16-lane row gave its segment back to decide() (an N where a class count was needed, a k with
+ *        more than 16 runs and no skip slot left, a failed skip check).   n <= TREW_DEBUG_COUNTERS entries are written. */
+#define TREW_DEBUG_COUNTERS 6
 int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n);
 
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(capi.EXPORTED_SYMBOLS)
     for s in declared:
         assert getattr(lib, s) is not None
-    assert lib.trew_hip_abi_version() == 3
+    assert lib.trew_hip_abi_version() == 4
 
 
 def test_pack_reads_matches_codes_table():

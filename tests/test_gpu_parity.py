@@ -1183,9 +1183,11 @@ def test_gathered_exchange_buffer():
             hdr = np.zeros(1, dtype=capi.ROW_DTYPE)
             for i, c in enumerate(ctxs):
                 base = gathered + i * (1 + cap) * row_bytes
-                assert c.collect_device(base + row_bytes, cap) == n_rows[i]
-                hdr["count"] = n_rows[i]
-                c._chk(c.lib.trew_hip_memcpy_h2d(c.ctx, base, hdr.ctypes.data, row_bytes), "h2d")
+                # rows and header written on the device (trew_hip_collect_slice_device): what allreduce_table_device does
+                assert c.collect_slice_device(base, cap, None, want_count=True) == n_rows[i]
+                back = np.zeros(1, dtype=capi.ROW_DTYPE)
+                c._chk(c.lib.trew_hip_memcpy_d2h(c.ctx, back.ctypes.data, base, row_bytes), "d2h")
+                assert (int(back["count"][0]), int(back["k"][0]), int(back["table"][0]), int(back["word_lo"][0])) == (n_rows[i], 0, 0, 0)
             for i, c in enumerate(ctxs):
                 assert c.add_gathered_device(gathered, 3, i, cap) == max(n_rows)
                 assert c.collect() == want  # every "rank" now holds the global sums
@@ -1197,9 +1199,7 @@ def test_gathered_exchange_buffer():
         gathered = ctxs[0].malloc(3 * (1 + cap) * row_bytes)
         for i, c in enumerate(ctxs):
             base = gathered + i * (1 + cap) * row_bytes
-            assert c.collect_device(base + row_bytes, cap) == n_rows[i]
-            hdr["count"] = n_rows[i]
-            c._chk(c.lib.trew_hip_memcpy_h2d(c.ctx, base, hdr.ctypes.data, row_bytes), "h2d")
+            assert c.collect_slice_device(base, cap, None, want_count=True) == n_rows[i]  # the header says how many there ARE
         assert ctxs[1].add_gathered_device(gathered, 3, 1, cap) == max(n_rows) > cap
         assert ctxs[1].collect() == parts[1]
         # a row out of range in a peer's slice: refused, nothing added, context still usable

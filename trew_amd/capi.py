@@ -20,6 +20,7 @@ FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (t
 FLAG_NO_TIMING = 64  # no HIP events per submit (last_timing unavailable)
 FLAG_COMPAT_G1 = 512  # pair mode, one slot: the reference's 64-bit pair branch as written (un-cleared temp_result_left)
 FLAG_TRACK_PRESSURE = 256  # the fill counters come back with every batch; table_pressure asks no device
+FLAG_DEBUG_NO_GROUP = 1024  # tests / A-B: every segment decided by a wave of its own (no decide_group)
 FLAG_DEBUG_WIDE_NO_WAIT = 128  # tests: the wide table never waits for a slot's ready bit (forces its time-out path)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
 
@@ -33,9 +34,9 @@ EXPORTED_SYMBOLS = (
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
     "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
     "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
-    "trew_hip_add_gathered_device", "trew_hip_debug_counters", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
+    "trew_hip_add_gathered_device", "trew_hip_collect_slice_device", "trew_hip_debug_counters", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
 )
-DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide")
+DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide", "group_punt")
 
 
 class Params(C.Structure):
@@ -120,6 +121,7 @@ def load():
     lib.trew_hip_add_rows_device.argtypes = [vp, vp, u64]
     lib.trew_hip_merge.argtypes = [vp, vp]
     lib.trew_hip_add_gathered_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(u64)]
+    lib.trew_hip_collect_slice_device.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
     lib.trew_hip_debug_counters.argtypes = [vp, C.POINTER(u64), i32]
     lib.trew_hip_table_pressure.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64]
@@ -347,6 +349,15 @@ class TrewHip:
         n = C.c_uint64(0)
         self._chk(self.lib.trew_hip_collect_device(self.ctx, d_rows, cap, C.byref(n)), "trew_hip_collect_device")
         return int(n.value)
+
+    def collect_slice_device(self, d_slice, slice_rows, consumer_stream=None, want_count=False):
+        """Compact every table into rows 1.. of the exchange slice d_slice (1 + slice_rows rows) and write its header row on
+        the device; the collective the caller issues on consumer_stream is ordered behind it without a host hop.  Returns the
+        row count when want_count (one host synchronisation), else None."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_collect_slice_device(self.ctx, d_slice, slice_rows, consumer_stream, C.byref(n) if want_count else None),
+                  "trew_hip_collect_slice_device")
+        return int(n.value) if want_count else None
 
     def add_rows_device(self, d_rows, n_rows):
         self._chk(self.lib.trew_hip_add_rows_device(self.ctx, d_rows, n_rows), "trew_hip_add_rows_device")

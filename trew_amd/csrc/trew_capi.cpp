@@ -858,6 +858,35 @@ extern "C" int trew_hip_collect_device(trew_hip_ctx *ctx, trew_hip_row *d_rows, 
     return compact_to(ctx, -1, d_rows, d_rows ? cap : 0, n_rows);
 }
 
+extern "C" int trew_hip_collect_slice_device(trew_hip_ctx *ctx, trew_hip_row *d_slice, uint64_t slice_rows, void *consumer_stream, uint64_t *n_rows) {
+    if (!ctx || !d_slice) return -1;
+    std::lock_guard<std::mutex> lk(ctx->table_mu);
+    if (int rc = sync_all(ctx)) return rc;
+    hipStream_t st = ctx->slots[0].stream;
+    if (consumer_stream) {  // whatever the caller's stream still does with the slice (a previous collective) comes first
+        HIPCHK(ctx, hipEventRecord(ctx->ev_producer, (hipStream_t) consumer_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_producer, 0));
+    } else {
+        HIPCHK(ctx, hipDeviceSynchronize());
+    }
+    if (!ctx->d_collect_n) HIPCHK(ctx, hipMalloc((void **) &ctx->d_collect_n, 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_collect_n, 0, 8, st));
+    HIPCHK(ctx, launch_compact(st, ctx->table, ctx->table_slots, ctx->wide.wide_log2_slots, -1, d_slice + 1, slice_rows, ctx->d_collect_n));
+    HIPCHK(ctx, launch_slice_finish(st, d_slice, slice_rows, ctx->d_collect_n, ctx->wide.spill_rows, ctx->wide.spill_n, ctx->wide.spill_cap));
+    if (consumer_stream) {  // the collective is ordered behind the header on the device: the host is not in the way
+        HIPCHK(ctx, hipEventRecord(ctx->ev_producer, st));
+        HIPCHK(ctx, hipStreamWaitEvent((hipStream_t) consumer_stream, ctx->ev_producer, 0));
+    }
+    if (n_rows || !consumer_stream) {
+        trew_hip_row h;
+        memset(&h, 0, sizeof(h));
+        HIPCHK(ctx, hipMemcpyAsync(&h, d_slice, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (n_rows) *n_rows = h.count;
+    }
+    return 0;
+}
+
 static int reset_locked(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipMemset(ctx->table.keys, 0, ctx->table_slots * 8));
     HIPCHK(ctx, hipMemset(ctx->table.counts, 0, ctx->table_slots * 8));
@@ -982,7 +1011,7 @@ extern "C" int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n) 
     u32 diag[kDiagWords], fb[kFallbackWords];
     HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
     HIPCHK(ctx, fallback_counters_read(fb));
-    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide]};
+    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide], fb[kFallbackGroupPunt]};
     for (int i = 0; i < n; i++) out[i] = i < TREW_DEBUG_COUNTERS ? v[i] : 0;
     return 0;
 }

@@ -65,6 +65,7 @@ enum {
     kFallbackStrictRerun = 0,   // decide(): a speculative skip failed its check and the segment was decided again, every k counted
     kFallbackWindows = 1,       // eval_runs(): more than 64 runs, classes counted per window (eval_k_windows)
     kFallbackWideSpin = 2,      // table_add_wide(): gave up waiting for a slot's ready bit (a duplicate slot may follow; collect merges)
+    kFallbackGroupPunt = 3,     // decide_group(): a row gave its segment back (an N, too many heavy k, a failed skip check) and decide() took it
     kFallbackWords = 4
 };
 

@@ -30,6 +30,7 @@
 //   prefilter.inc      filter_kernel<NW> (general path + uniform-geometry fast path)
 //   count_table.inc    table_add / table_add_wide / spill log
 //   exact_core.inc     LDS working set, eval_k / eval_runs (Lemma A), lane_bounds, decide, emit_k, run_short, run_segment
+//   decide_group.inc   decide_group (four segments in lock step, 16 lanes each), run_short_group
 //   driver_long.inc    run_long        driver_pair.inc   run_pair
 //   exact_kernel.inc   exact_kernel<NW, MODE, WT>
 //   table_kernels.inc  add-rows / compaction kernels      synth_kernels.inc  workload generators
@@ -55,6 +56,7 @@ typedef unsigned __int128 u128;  // 2k-bit words for k in (32, 64] (k_mer_check_
 #include "kernels/prefilter.inc"
 #include "kernels/count_table.inc"
 #include "kernels/exact_core.inc"
+#include "kernels/decide_group.inc"
 #include "kernels/driver_long.inc"
 #include "kernels/driver_pair.inc"
 #include "kernels/exact_kernel.inc"
@@ -268,6 +270,13 @@ hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wi
                           unsigned long long *d_n) {
     const u64 total = n_slots + (1ull << wide_log2_slots);
     hipLaunchKernelGGL(table_compact_kernel, dim3((u32) ((total + 255) / 256)), dim3(256), 0, st, T, n_slots, table, d_rows, cap, d_n);
+    return hipGetLastError();
+}
+
+// header + spill log of a rank's exchange slice, behind launch_compact on the same stream (see table_slice_finish_kernel)
+hipError_t launch_slice_finish(hipStream_t st, trew_hip_row *d_slice, u64 slice_rows, const unsigned long long *d_n, const trew_hip_row *d_spill_rows,
+                               const u32 *d_spill_n, u32 spill_cap) {
+    hipLaunchKernelGGL(table_slice_finish_kernel, dim3((spill_cap + 255u) / 256u), dim3(256), 0, st, d_slice, slice_rows, d_n, d_spill_rows, d_spill_n, spill_cap);
     return hipGetLastError();
 }
 

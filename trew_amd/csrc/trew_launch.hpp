@@ -25,6 +25,8 @@ hipError_t launch_pack_ascii(hipStream_t st, const unsigned char *d_bases, const
                              u32 uniform_length, u64 n_reads, u64 n_triples, u32 *d_words);
 hipError_t launch_compact(hipStream_t st, const DevTable &T, u64 n_slots, u32 wide_log2_slots, int table, trew_hip_row *d_rows, u64 cap,
                           unsigned long long *d_n);
+hipError_t launch_slice_finish(hipStream_t st, trew_hip_row *d_slice, u64 slice_rows, const unsigned long long *d_n, const trew_hip_row *d_spill_rows,
+                               const u32 *d_spill_n, u32 spill_cap);
 hipError_t launch_synth_short(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);
 hipError_t launch_synth_long(hipStream_t st, u64 seed, u64 first, u64 n, const u32 *d_qtable, const u32 *d_offsets, u32 *d_words);
 hipError_t launch_synth_pair(hipStream_t st, u64 seed, u64 first, u64 n, u32 len, u32 *d_words);

@@ -28,6 +28,10 @@ import torch.distributed as dist
 from .capi import TABLE_NAMES
 
 _MASK63 = (1 << 63) - 1
+# Rows per rank in the exchange buffer of allreduce_table_device.  A 125 M-read share of config 5 (1 B reads over 8 GPUs) leaves
+# about 60 k rows in a rank's tables; twice that, so that a real 8-rank run does not sit at the retry boundary (32 B per row:
+# 4 MiB per slice, 32 MiB gathered on 8 ranks).
+DEFAULT_SLICE_ROWS = 1 << 17
 
 
 def _to_i64(x: int) -> int:
@@ -177,8 +181,9 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False, row
     """The reduction bench.py uses for N > 1 with backend "nccl" (= RCCL): ONE collective, nothing leaves HBM until the
     final rows, no host round trip between the compaction and the merge.
 
-      1. trew_hip_collect_device compacts this rank's table straight into its slice of a fixed-capacity exchange buffer:
-         1 + cap rows of 32 B (table, k, word, count), row 0 = header carrying the row count;
+      1. trew_hip_collect_slice_device compacts this rank's table straight into its slice of a fixed-capacity exchange buffer:
+         1 + cap rows of 32 B (table, k, word, count), row 0 = header carrying the row count, written by a kernel behind the
+         compaction (the collective's stream waits for it on the device: no host hop);
       2. ONE all_gather_into_tensor of the slices -- RCCL over xGMI, KB..MB, latency-bound;
       3. trew_hip_add_gathered_device: one kernel over the gathered buffer adds every OTHER rank's rows into this rank's
          device table (own slice skipped by index; ordered behind the collective on the device, by an event) -- the table
@@ -202,7 +207,7 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False, row
         return ctx.collect_rows()
     rank = dist.get_rank(group)
     words = ROW_DTYPE.itemsize // 8
-    cap = getattr(ctx, "_dev_rows_cap", 1 << 16)
+    cap = getattr(ctx, "_dev_rows_cap", DEFAULT_SLICE_ROWS)
     on_gpu = torch.device(device).type == "cuda"
     while True:
         bufs = getattr(ctx, "_exchange_bufs", None)
@@ -211,10 +216,11 @@ def allreduce_table_device(ctx, device, group=None, force_collectives=False, row
             gathered = torch.empty((world * (1 + cap), words), dtype=torch.int64, device=device)
             ctx._exchange_bufs = bufs = ((cap, world, str(device)), local, gathered)
         _, local, gathered = bufs
-        n = ctx.collect_device(local[1:].data_ptr(), cap)  # synchronises the context's streams; rows beyond cap are not written
-        local[0, words - 1] = n  # header: the count sits where a row keeps its count (trew_hip_row.count)
-        dist.all_gather_into_tensor(gathered, local, group=group)
         stream = torch.cuda.current_stream(device).cuda_stream if on_gpu else None
+        # rows 1.. and the header row (count where a row keeps its count) are written by kernels on the context's stream; the
+        # collective's stream waits for them on the device -- the host neither reads the count nor writes the header
+        ctx.collect_slice_device(local.data_ptr(), cap, stream)
+        dist.all_gather_into_tensor(gathered, local, group=group)
         most = ctx.add_gathered_device(gathered.data_ptr(), world, rank, cap, stream)
         if most <= cap:
             break
