@@ -227,8 +227,10 @@ int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *t
  * out[2] wide table (k > 32): gave up waiting for a slot's ready bit (collect merges the duplicate slot this can leave)
  * out[3] keys inserted into the narrow table, out[4] into the wide table
  * out[5] decide_group(): a 16-lane row gave its segment back to decide() (an N where a class count was needed, a k with
- *        more than 16 runs and no skip slot left, a failed skip check).   n <= TREW_DEBUG_COUNTERS entries are written. */
-#define TREW_DEBUG_COUNTERS 6
+ *        more than 16 runs and no skip slot left, a failed skip check)
+ * out[6] reads of the group pass routed and recorded by the wave-per-segment code, out[7] whose k_mer_target was counted by it.
+ * n <= TREW_DEBUG_COUNTERS entries are written. */
+#define TREW_DEBUG_COUNTERS 10
 int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n);
 
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for

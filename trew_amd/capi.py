@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = (
     "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
     "trew_hip_add_gathered_device", "trew_hip_collect_slice_device", "trew_hip_debug_counters", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
 )
-DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide", "group_punt")
+DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide", "group_punt", "group_routed", "group_target", "ab_6", "ab_7")
 
 
 class Params(C.Structure):

@@ -1011,7 +1011,7 @@ extern "C" int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n) 
     u32 diag[kDiagWords], fb[kFallbackWords];
     HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
     HIPCHK(ctx, fallback_counters_read(fb));
-    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide], fb[kFallbackGroupPunt]};
+    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide], fb[kFallbackGroupPunt], fb[kFallbackGroupRouted], fb[kFallbackGroupTarget], fb[6], fb[7]};
     for (int i = 0; i < n; i++) out[i] = i < TREW_DEBUG_COUNTERS ? v[i] : 0;
     return 0;
 }

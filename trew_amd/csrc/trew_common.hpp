@@ -66,7 +66,9 @@ enum {
     kFallbackWindows = 1,       // eval_runs(): more than 64 runs, classes counted per window (eval_k_windows)
     kFallbackWideSpin = 2,      // table_add_wide(): gave up waiting for a slot's ready bit (a duplicate slot may follow; collect merges)
     kFallbackGroupPunt = 3,     // decide_group(): a row gave its segment back (an N, too many heavy k, a failed skip check) and decide() took it
-    kFallbackWords = 4
+    kFallbackGroupRouted = 4,   // run_short_group(): a read routed and recorded by run_short_routed instead of in row space
+    kFallbackGroupTarget = 5,   // run_short_group(): k_mer_target of a read counted by target() (more than 16 runs in the whole read)
+    kFallbackWords = 8
 };
 
 // device scratch of the row-adding entry points (table_check_rows_kernel & co): validation is a pass of its own, so an add is all or nothing

@@ -155,7 +155,7 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
 
 hipError_t fallback_counters_read(u32 *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fallback), sizeof(u32) * kFallbackWords); }
 hipError_t fallback_counters_clear() {
-    const u32 z[kFallbackWords] = {0, 0, 0, 0};
+    const u32 z[kFallbackWords] = {0, 0, 0, 0, 0, 0, 0, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fallback), z, sizeof(z));
 }
 
