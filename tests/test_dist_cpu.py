@@ -83,3 +83,22 @@ def test_single_process_passthrough_and_shards():
     cover = [shard_range(n, r, w) for r in range(w)]
     assert cover[0][0] == 0 and cover[-1][1] == n
     assert all(cover[i][1] == cover[i + 1][0] for i in range(w - 1))
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_refuses_a_mismatch():
+    """bench.py --gpus 2 started plainly (no torchrun, no WORLD_SIZE) launches two ranks itself -- before torch or HIP is
+    imported -- and relays rank 0's line; with a WORLD_SIZE that contradicts --gpus it refuses instead of running a job of
+    another size.  --rehearse-launch keeps the GPU out of it (this box has none): the ranks meet over gloo and are counted."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rehearsal"] is True
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr

@@ -619,6 +619,72 @@ def test_fuzz_all_modes(seed):
         assert t.collect() == want, ("long", kw, sl)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_group_pass_matches_oracle_and_wave_per_segment(seed):
+    """The exact kernel's group pass (four segments in lock step, 16 lanes each: decide_group, row-space routing, k_mer_target as
+    a whole-read row count) only runs on batches whose halves fit 3- or 5-word masks, which the fuzz above (reads up to 1000
+    bases) never is.  Ragged batches of short reads -- noisy repeats, junctions, N, low-complexity words, every baseline
+    combination, k ranges of 1 .. 32 values -- against the oracle, and against the same library with every segment decided by
+    a wave of its own (TREW_FLAG_DEBUG_NO_GROUP)."""
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(4100 + seed)
+    mn = rnd.choice([3, 4, 5, 5, 6, 9])
+    mx = max(mn, rnd.choice([mn, 12, 20, 31, 32, 32, mn + 31 if mn + 31 <= 32 else 32]))
+    low = rnd.choice([0.5, 0.5, 0.3, 0.51, 2 / 3, 0.75, 1.0])
+    high = max(low, rnd.choice([0.8, 0.6, 0.9, 0.9, 1.0]))
+    kw = dict(min_mer=mn, max_mer=mx, low=low, high=high)
+    maxlen = rnd.choice([150, 151, 190, 250, 318])
+    reads = []
+    for _ in range(1500):
+        n = rnd.choice([maxlen, maxlen, rnd.randint(4 * mn, maxlen), rnd.randint(1, maxlen)])
+        kind = rnd.random()
+        if kind < 0.1:
+            s = "".join(rnd.choice("ACGT") for _ in range(n))
+        elif kind < 0.17:
+            s = "".join(rnd.choice("AT") for _ in range(n))
+        else:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([rnd.randint(1, 12), rnd.randint(1, 40), 6])))
+            s = mutate(periodic(unit, n, rnd.randint(0, 11)), rnd, p_sub=rnd.choice([0, 0.01, 0.01, 0.03, 0.08, 0.2]), p_n=rnd.choice([0, 0, 0, 0.005, 0.02, 0.1]))
+            r = rnd.random()
+            if r < 0.25:  # junction at the middle or anywhere
+                cut = rnd.choice([n // 2, rnd.randint(0, n)])
+                tail = "".join(rnd.choice("ACGT") for _ in range(n - cut)) if rnd.random() < 0.5 else periodic("".join(rnd.choice("ACGT") for _ in range(rnd.randint(2, 20))), n - cut)
+                s = s[:cut] + tail if rnd.random() < 0.5 else tail + s[:cut]
+        reads.append(s[:n].encode())
+    want = O.run_short(O.OracleParams(**kw), reads)
+    got = {}
+    for flags in (0, T.FLAG_DEBUG_NO_GROUP):
+        with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, flags=flags, **kw) as t:
+            t.reset_tables()  # the fall-back counters are per device: start from zero
+            t.submit_reads(reads)
+            t.wait()
+            got[flags] = t.collect()
+            c = t.debug_counters()
+            if flags:
+                assert c["group_punt"] == c["group_routed"] == c["group_target"] == 0, c  # the flag really turns the pass off
+    assert got[0] == want, ("group pass", kw, maxlen, _table_diff(got[0], want))
+    assert got[T.FLAG_DEBUG_NO_GROUP] == want, ("wave per segment", kw, maxlen)
+
+
+def test_group_pass_takes_almost_every_read_of_the_bench_workload():
+    """On the synthetic reads of config 2 the group pass hands back under 2 % of the flagged reads (round 4: 0.8 %) -- N, noisy
+    repeats and junction reads included -- and the tables equal the oracle's."""
+    buf, st, nd = capi.synth_short_ascii(20250218, 3_000_000, 200000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    want = O.run_short(O.OracleParams(), reads)
+    with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 23) as t:
+        t.reset_tables()
+        t.submit_reads(reads)
+        t.wait()
+        assert t.collect() == want
+        c = t.debug_counters()
+        flagged = t.last_timing(0)[2]
+        assert flagged > 3000 and c["group_routed"] + c["group_target"] < 0.02 * flagged, (c, flagged)
+
+
 def test_regressions_found_by_fuzzing():
     # (1) LDS mask words: a 176-base segment uses the NW=10 kernels but only 3 mask words; the run-based
     #     path once wrote past them and cleared the N mask of the first bases (leading N became valid)

@@ -81,6 +81,22 @@ def test_bench_two_ranks_one_gpu_gloo_rehearsal():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["value"] > 0 and out["table_rows"] > 1000
 
 
+def test_bench_gpus_2_launched_plainly_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that forgets torchrun would do): bench.py starts the
+    two ranks itself before it touches the GPU, relays rank 0's line, and the line says n_gpus 2 and carries exchange_ms."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--exchange", "device", "--reads", "1500000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["table_rows"] > 1000 and out["exchange_ms"] > 0
+
+
 def test_two_ranks_device_tensor_exchange_against_the_oracle():
     """allreduce_table_device (collect_device -> all_gather of device tensors -> add_rows_device), the reduction of the nccl
     runs, with two real ranks: gloo moves the device tensors, both ranks share this GPU.  Merged tables = oracle on all reads."""
