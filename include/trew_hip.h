@@ -65,6 +65,9 @@ enum {
                                 if that pair's four segments chain, else to `forward` (kmer.cpp:378-399, 438-455).  Batches must
                                 be submitted in file order; this reproduces the reference run with ONE consumer thread (with
                                 more its output depends on scheduling).  Default: the cleared semantics. */
+    TREW_FLAG_DEBUG_NO_JOINT = 2048, /* tests: the prefilter's uniform path judges every segment in a k loop of its own instead of both
+                                halves of a read in one (filter_halves_uni); the flagged reads may differ by a few (odd lengths use a
+                                joint threshold), the tables never */
     TREW_FLAG_DEBUG_NO_GROUP = 1024, /* tests and A/B runs: the exact kernel gives every segment a wave of its own (decide()) instead
                                 of deciding four segments in lock step, 16 lanes each (decide_group); results are identical */
     TREW_FLAG_TRACK_PRESSURE = 256 /* every batch ends with a copy of the table's fill counters into pinned host memory, and
@@ -230,8 +233,13 @@ int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, uint64_t *t
  *        more than 16 runs and no skip slot left, a failed skip check)
  * out[6] reads of the group pass routed and recorded by the wave-per-segment code, out[7] whose k_mer_target was counted by it.
  * n <= TREW_DEBUG_COUNTERS entries are written. */
-#define TREW_DEBUG_COUNTERS 10
+#define TREW_DEBUG_COUNTERS 8
 int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n);
+
+/* Diagnostic: the unit indices (reads, or pairs in pair mode) the prefilter of the last submit on `slot` handed to the exact
+ * kernel, in worklist order (after trew_hip_wait).  *n receives their number even when it exceeds cap.  Tests use it to assert
+ * that the prefilter is sound: every read with a (segment, k) that k_mer_check accepts (kmer.cpp:2221-2258) must be there. */
+int trew_hip_debug_worklist(trew_hip_ctx *ctx, int slot, uint32_t *units, uint64_t cap, uint64_t *n);
 
 /* Per-read results of the last submit on `slot` (after trew_hip_wait): for
  * TREW_MODE_SEGMENT the (k_high, k_low, MAX_SEQ at k_high, MAX_SEQ at k_low)

@@ -101,6 +101,24 @@ def test_cli_short_crlf_and_lowercase(tmp_path):
     assert run("short", "5", "32", a) == want
 
 
+@pytest.mark.parametrize("extra", [[], ["--host_pack"], ["--serial_reader"]])
+def test_cli_fastq_of_empty_sequence_lines(tmp_path, extra):
+    """A FASTQ whose sequence lines are all empty (one length: zero) used to close a 'uniform' text batch without a length and
+    die in trew_hip_submit_ascii; the reference and the CPU-pack path print the empty sections.  All readers must."""
+    p = str(tmp_path / "empty_lines.fastq")
+    write_fastq(p, [b""] * 500)
+    out = run("short", "5", "32", p, "-t", "3", *extra)
+    assert out == [">H:" + os.path.realpath(p), ">L:" + os.path.realpath(p), ">Putative_TRM", "NO_PUTATIVE_TRM,-1"]
+    # and the same among ordinary reads
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 3000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    mixed = reads[:1500] + [b""] * 40 + reads[1500:]
+    p2 = str(tmp_path / "mixed.fastq")
+    write_fastq(p2, mixed)
+    want = expected([(p2, O.run_short(O.OracleParams(), mixed))], 5)
+    assert run("short", "5", "32", p2, "-t", "3", *extra) == want
+
+
 def test_cli_pair(tmp_path):
     b1, b2, st, nd = capi.synth_pair_ascii(20250218, 0, 30000, 150)
     r1 = [b1[s:e + 1] for s, e in zip(st, nd)]

@@ -1041,6 +1041,39 @@ def _fixed_len_reads(rnd, count, n):
     return out
 
 
+@pytest.mark.parametrize("n", [150, 151, 149, 101, 100, 131, 189])
+def test_joint_halves_loop_is_sound(n):
+    """The prefilter's joint k loop (both halves of a read in one loop, filter_halves_uni; odd lengths judge the longer right half
+    by its first L bases against a joint threshold row) is switched off whenever per-k masks are asked for, so
+    test_uniform_fast_path_is_sound never sees it.  Here its verdict is observed where it lands: the worklist.  Every read for
+    which the oracle records anything -- i.e. some (segment, k) passes k_mer_check -- must be among the flagged units, with the
+    joint loop (default) and without it (TREW_FLAG_DEBUG_NO_JOINT); the tables of both runs equal the oracle's."""
+    import random
+
+    rnd = random.Random(7700 + n)
+    reads = _fixed_len_reads(rnd, 3000, n)
+    p = O.OracleParams()
+    passing = {i for i, r in enumerate(reads) if any(len(tb) for tb in O.run_short(p, [r]).values())}
+    assert len(passing) > 300
+    want = O.run_short(p, reads)
+    words, offs, lens = capi.pack_reads(reads)
+    stride = 3 * ((n + 31) // 32)
+    flagged = {}
+    for flags in (0, T.FLAG_DEBUG_NO_JOINT):
+        with T.TrewHip(mode=T.MODE_SHORT, max_batch_reads=len(reads) + 8, max_batch_words=1 << 20, flags=flags) as t:
+            b = capi.Batch(words.ctypes.data, len(words), None, None, n, stride, len(reads), 0, 0)  # uniform batch: the fast path
+            t.submit(b, 0)
+            t.wait(0)
+            wl = t.debug_worklist(0)
+            flagged[flags] = set(int(x) for x in wl)
+            assert len(flagged[flags]) == len(wl)  # no unit twice
+            missing = passing - flagged[flags]
+            assert not missing, ("a read with a passing (segment, k) was dropped by the prefilter", flags, sorted(missing)[:5])
+            assert t.collect() == want
+    # the two loops may flag slightly different false positives (joint threshold of odd lengths), never fewer true ones
+    assert len(flagged[0] ^ flagged[T.FLAG_DEBUG_NO_JOINT]) < 0.05 * len(reads)
+
+
 @pytest.mark.parametrize("n", [150, 151, 126, 190, 142, 66, 96])
 def test_uniform_fast_path_is_sound(n):
     """Candidate masks of the prefilter's uniform-geometry fast path, per segment, against the oracle's class counts: every k

@@ -12,6 +12,7 @@ from .capi import (  # noqa: F401
     FLAG_TRACK_PRESSURE,
     FLAG_COMPAT_G1,
     FLAG_DEBUG_NO_GROUP,
+    FLAG_DEBUG_NO_JOINT,
     FLAG_DEBUG_WIDE_NO_WAIT,
     MODE_LONG,
     MODE_PAIR,

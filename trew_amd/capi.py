@@ -20,6 +20,7 @@ FLAG_DEBUG_POISON_LDS = 32  # the exact kernel starts from garbage-filled LDS (t
 FLAG_NO_TIMING = 64  # no HIP events per submit (last_timing unavailable)
 FLAG_COMPAT_G1 = 512  # pair mode, one slot: the reference's 64-bit pair branch as written (un-cleared temp_result_left)
 FLAG_TRACK_PRESSURE = 256  # the fill counters come back with every batch; table_pressure asks no device
+FLAG_DEBUG_NO_JOINT = 2048  # tests: the prefilter's uniform path without the joint k loop of both halves
 FLAG_DEBUG_NO_GROUP = 1024  # tests / A-B: every segment decided by a wave of its own (no decide_group)
 FLAG_DEBUG_WIDE_NO_WAIT = 128  # tests: the wide table never waits for a slot's ready bit (forces its time-out path)
 TABLE_NAMES = ("forward_high", "forward_low", "backward_high", "backward_low", "both_high", "both_low")
@@ -34,9 +35,9 @@ EXPORTED_SYMBOLS = (
     "trew_pack_pairs", "trew_hip_host_alloc", "trew_hip_host_free", "trew_hip_device_count",
     "trew_synth_long_lengths", "trew_synth_long_ascii", "trew_synth_long_device",
     "trew_hip_collect_device", "trew_hip_add_rows_device", "trew_hip_merge", "trew_hip_table_pressure",
-    "trew_hip_add_gathered_device", "trew_hip_collect_slice_device", "trew_hip_debug_counters", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
+    "trew_hip_add_gathered_device", "trew_hip_collect_slice_device", "trew_hip_debug_counters", "trew_hip_debug_worklist", "trew_hip_submit_ascii", "trew_hip_pack_ascii",
 )
-DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide", "group_punt", "group_routed", "group_target", "ab_6", "ab_7")
+DEBUG_COUNTERS = ("strict_rerun", "windows_fallback", "wide_spin_timeout", "inserted", "inserted_wide", "group_punt", "group_routed", "group_target")
 
 
 class Params(C.Structure):
@@ -123,6 +124,7 @@ def load():
     lib.trew_hip_add_gathered_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, u64, vp, C.POINTER(u64)]
     lib.trew_hip_collect_slice_device.argtypes = [vp, vp, u64, vp, C.POINTER(u64)]
     lib.trew_hip_debug_counters.argtypes = [vp, C.POINTER(u64), i32]
+    lib.trew_hip_debug_worklist.argtypes = [vp, i32, vp, u64, C.POINTER(u64)]
     lib.trew_hip_table_pressure.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     lib.trew_hip_segment_results.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, u64]
     lib.trew_hip_filter_masks.argtypes = [vp, C.POINTER(Batch), vp, i32]
@@ -375,6 +377,15 @@ class TrewHip:
         out = (C.c_uint64 * len(DEBUG_COUNTERS))()
         self._chk(self.lib.trew_hip_debug_counters(self.ctx, out, len(DEBUG_COUNTERS)), "trew_hip_debug_counters")
         return dict(zip(DEBUG_COUNTERS, (int(x) for x in out)))
+
+    def debug_worklist(self, slot=0):
+        """Unit indices the prefilter of the last submit on `slot` flagged (numpy uint32, worklist order)."""
+        n = C.c_uint64(0)
+        self._chk(self.lib.trew_hip_debug_worklist(self.ctx, slot, None, 0, C.byref(n)), "trew_hip_debug_worklist")
+        out = np.zeros(int(n.value), dtype=np.uint32)
+        if len(out):
+            self._chk(self.lib.trew_hip_debug_worklist(self.ctx, slot, out.ctypes.data, len(out), C.byref(n)), "trew_hip_debug_worklist")
+        return out
 
     def merge_from(self, other):
         """Add every row of `other`'s tables (another context, same or another GPU) into this context's tables."""

@@ -617,7 +617,10 @@ static void block_worker_loop(Scanner *s, Worker *w, BlockJob *job) {
             b.bases = (const char *) h_bases;
             b.n_bytes = acc_bytes;
             b.n_reads = acc_reads;
-            if (same_len && !job->long_mode) {  // an ordinary Illumina run: no index arrays, and the prefilter takes its uniform-geometry path
+            // an ordinary Illumina run: no index arrays, and the prefilter takes its uniform-geometry path.  (A batch of EMPTY
+            // sequence lines has one length too, but a uniform batch needs a length: it goes with index arrays and yields nothing,
+            // as in the reference.)
+            if (same_len && w->tmp_len[0] > 0 && !job->long_mode) {
                 b.uniform_length = w->tmp_len[0];
             } else {
                 uint32_t *arr = (uint32_t *) (h_bases - 12ull * acc_reads);

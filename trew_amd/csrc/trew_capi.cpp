@@ -80,6 +80,13 @@ struct trew_hip_ctx {
     // queued in microseconds.  The link carries one copy at a time anyway, so one stream loses no bandwidth.
     hipStream_t copy_stream = nullptr;
     std::mutex copy_mu;  // a batch's copies and the event behind them are queued as one unit
+    // Fills of device memory (the tables at init and reset, the buffers at init) are queued on this stream and every other stream
+    // of the context is made to wait for the event behind them -- on the device.  hipMemset on the null stream returns at once
+    // (2 us for 256 MiB, tools/memset_probe.hip) while the fill takes 0.13 ms, and the slots' non-blocking streams do not wait for
+    // the null stream: a batch submitted right behind it scanned into a table that was still being cleared (round 3's "empty
+    // tables once in 270 runs").  Stream order instead of a host wait: init / reset do not stall the submitting threads.
+    hipStream_t fill_stream = nullptr;
+    hipEvent_t ev_filled = nullptr;
     int n_cu = 256;
     // persistent scratch of trew_hip_collect (device-side compaction)
     unsigned long long *d_collect_n = nullptr;
@@ -160,6 +167,15 @@ static float conservative_lowf(double low) {
     return f;
 }
 
+// an event behind everything queued on the fill stream so far; the copy stream and every slot's stream wait for it on the device
+static int order_behind_fills(trew_hip_ctx *ctx) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev_filled, ctx->fill_stream));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_filled, 0));
+    for (auto &s : ctx->slots)
+        if (s.stream) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->ev_filled, 0));
+    return 0;
+}
+
 extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) {
     if (!params || !out) {
         g_init_error = "trew_hip_init: null argument";
@@ -217,14 +233,16 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         trew_hip_destroy(ctx);
         return -3;
     };
+    if ((e = hipStreamCreateWithFlags(&ctx->fill_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_filled, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     ctx->table_slots = 1ull << p.table_log2_slots;
     ctx->table.log2_part_slots = p.table_log2_slots - kTablePartBits;
     if ((e = hipMalloc((void **) &ctx->table.keys, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table keys)", e);
     if ((e = hipMalloc((void **) &ctx->table.counts, ctx->table_slots * 8)) != hipSuccess) return bail("hipMalloc(table counts)", e);
     if ((e = hipMalloc((void **) &ctx->table.overflow, kDiagWords * 4)) != hipSuccess) return bail("hipMalloc(overflow)", e);
-    if ((e = hipMemset(ctx->table.keys, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->table.counts, 0, ctx->table_slots * 8)) != hipSuccess) return bail("hipMemset", e);
-    if ((e = hipMemset(ctx->table.overflow, 0, kDiagWords * 4)) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMemsetAsync(ctx->table.keys, 0, ctx->table_slots * 8, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+    if ((e = hipMemsetAsync(ctx->table.counts, 0, ctx->table_slots * 8, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+    if ((e = hipMemsetAsync(ctx->table.overflow, 0, kDiagWords * 4, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
     // wide entries (k > 32) are rare: a quarter of the slots
     ctx->wide.wide_log2_slots = std::max<u32>(10u, p.table_log2_slots - 2u);
     {
@@ -232,7 +250,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         u64 **arr[4] = {&ctx->wide.wtag, &ctx->wide.wlo, &ctx->wide.whi, &ctx->wide.wcount};
         for (auto a : arr) {
             if ((e = hipMalloc((void **) a, wb)) != hipSuccess) return bail("hipMalloc(wide table)", e);
-            if ((e = hipMemset(*a, 0, wb)) != hipSuccess) return bail("hipMemset", e);
+            if ((e = hipMemsetAsync(*a, 0, wb, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         }
         // spill log: 1/16 of the table's slots, at least 64 k rows
         ctx->wide.spill_cap = (u32) std::max<u64>(1ull << 16, ctx->table_slots >> 4);
@@ -252,7 +270,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             ctx->g1_carry_cap = 1u << 16;
             if ((e = hipMalloc((void **) &ctx->g1.log, (size_t) ctx->g1.log_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(G1 log)", e);
             if ((e = hipMalloc((void **) &ctx->g1.counters, 16)) != hipSuccess) return bail("hipMalloc(G1 counters)", e);
-            if ((e = hipMemset(ctx->g1.counters, 0, 16)) != hipSuccess) return bail("hipMemset", e);
+            if ((e = hipMemsetAsync(ctx->g1.counters, 0, 16, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
             if ((e = hipMalloc((void **) &ctx->g1.pair_flags, (size_t) (p.max_batch_reads / 2 + 64))) != hipSuccess) return bail("hipMalloc(G1 pair flags)", e);
             for (auto &cb : ctx->g1_carry)
                 if ((e = hipMalloc((void **) &cb, (size_t) ctx->g1_carry_cap * sizeof(trew_hip_row))) != hipSuccess) return bail("hipMalloc(G1 carry)", e);
@@ -260,6 +278,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         DevTableG1 tbl;
         tbl.t = ctx->table;
         tbl.g = ctx->g1;
+        tbl.w = ctx->wide;
         if (p.flags & TREW_FLAG_DEBUG_NO_EMIT) tbl.t.log2_part_slots = 0xffffffffu;  // cached_add drops every row
         ctx->table_g1 = tbl;
     }
@@ -276,14 +295,14 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             // +8 words of slack: the exact kernel fetches whole 64-word heads of a read
             const size_t words = 2 * (size_t) p.max_batch_reads + (size_t) p.max_batch_words + 8;
             if ((e = hipMalloc((void **) &s.d_buf, words * 4)) != hipSuccess) return bail("hipMalloc(batch buffer)", e);
-            if ((e = hipMemset(s.d_buf, 0, words * 4)) != hipSuccess) return bail("hipMemset", e);
+            if ((e = hipMemsetAsync(s.d_buf, 0, words * 4, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
             s.d_offsets = s.d_buf;
             s.d_lengths = s.d_buf + p.max_batch_reads;
             s.d_words = s.d_buf + 2 * (size_t) p.max_batch_reads;
         }
         if (p.max_batch_ascii_bytes) {
             if ((e = hipMalloc((void **) &s.d_ascii, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMalloc(text buffer)", e);
-            if ((e = hipMemset(s.d_ascii, 0, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMemset", e);
+            if ((e = hipMemsetAsync(s.d_ascii, 0, p.max_batch_ascii_bytes + 256, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         }
         if ((e = hipMalloc((void **) &s.d_thr, kThrRows * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
         if ((e = hipHostMalloc((void **) &s.h_thr, kThrRows * kThrRow * sizeof(int2) + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
@@ -291,7 +310,7 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         memset(s.h_seen, 0, kDiagWords * 4);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
-        if ((e = hipMemset(s.d_wl_count, 0, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMemset", e);
+        if ((e = hipMemsetAsync(s.d_wl_count, 0, 2 * kWlCountBytes, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         if (p.mode == TREW_MODE_SEGMENT) {
             if ((e = hipMalloc((void **) &s.res.k_high, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
             if ((e = hipMalloc((void **) &s.res.k_low, p.max_batch_reads * 4)) != hipSuccess) return bail("hipMalloc", e);
@@ -304,10 +323,12 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             for (int j = 0; j < 3; j++)
                 if ((e = hipEventCreate(&s.ev[i][j])) != hipSuccess) return bail("hipEventCreate", e);
     }
-    // hipMemset is queued on the null stream and may return before it has run; the slots' streams are non-blocking (they do not
-    // wait for the null stream), so a first batch submitted right away could have its worklist counters or table rows wiped
-    // by a memset that was still pending -- seen once in four hundred fuzz seeds as a context that returned empty tables
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail("hipDeviceSynchronize", e);
+    // every stream of the context starts behind the fills (see fill_stream)
+    if (int rc = order_behind_fills(ctx)) {
+        g_init_error = g_thread_error;
+        trew_hip_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
     return 0;
 }
@@ -336,7 +357,10 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
         if (s.ev_copied) (void) hipEventDestroy(s.ev_copied);
         if (s.stream) (void) hipStreamDestroy(s.stream);
     }
+    if (ctx->fill_stream) (void) hipStreamSynchronize(ctx->fill_stream);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->fill_stream) (void) hipStreamDestroy(ctx->fill_stream);
+    if (ctx->ev_filled) (void) hipEventDestroy(ctx->ev_filled);
     if (ctx->table.keys) (void) hipFree(ctx->table.keys);
     if (ctx->table.counts) (void) hipFree(ctx->table.counts);
     if (ctx->table.overflow) (void) hipFree(ctx->table.overflow);
@@ -754,6 +778,7 @@ static int check_diag(trew_hip_ctx *ctx, u32 (&diag)[kDiagWords]) {
     if (diag[kDiagWorklistDrop]) return fail(ctx, "internal error: the prefilter worklist overflowed (survivors were dropped)");
     if (diag[kDiagIntentDrop]) return fail(ctx, "internal error: a pair logged more than 32 deferred emissions (some were dropped)");
     if (diag[kDiagG1Drop]) return fail(ctx, "TREW_FLAG_COMPAT_G1: the stale-row log of a batch overflowed (submit smaller batches)");
+    if (diag[kDiagKernarg]) return fail(ctx, "internal error: the exact kernel's table descriptor differs from its by-value argument (kernarg layout)");
     return 0;
 }
 
@@ -888,17 +913,20 @@ extern "C" int trew_hip_collect_slice_device(trew_hip_ctx *ctx, trew_hip_row *d_
 }
 
 static int reset_locked(trew_hip_ctx *ctx) {
-    HIPCHK(ctx, hipMemset(ctx->table.keys, 0, ctx->table_slots * 8));
-    HIPCHK(ctx, hipMemset(ctx->table.counts, 0, ctx->table_slots * 8));
-    HIPCHK(ctx, hipMemset(ctx->table.overflow, 0, kDiagWords * 4));
+    // the callers have synchronised every slot, so nothing reads or writes the tables; the fills are queued on the fill stream
+    // and every stream of the context waits for them on the device (see fill_stream) -- no host wait
+    hipStream_t fs = ctx->fill_stream;
+    HIPCHK(ctx, hipMemsetAsync(ctx->table.keys, 0, ctx->table_slots * 8, fs));
+    HIPCHK(ctx, hipMemsetAsync(ctx->table.counts, 0, ctx->table_slots * 8, fs));
+    HIPCHK(ctx, hipMemsetAsync(ctx->table.overflow, 0, kDiagWords * 4, fs));
     const size_t wb = (size_t) 8 << ctx->wide.wide_log2_slots;
-    HIPCHK(ctx, hipMemset(ctx->wide.wtag, 0, wb));
-    HIPCHK(ctx, hipMemset(ctx->wide.wlo, 0, wb));
-    HIPCHK(ctx, hipMemset(ctx->wide.whi, 0, wb));
-    HIPCHK(ctx, hipMemset(ctx->wide.wcount, 0, wb));
-    HIPCHK(ctx, fallback_counters_clear());
-    if (ctx->g1.counters) HIPCHK(ctx, hipMemset(ctx->g1.counters, 0, 16));  // a new input: nothing is left in the stale map
-    HIPCHK(ctx, hipStreamSynchronize(nullptr));  // the memsets above are null-stream work that the slots' non-blocking streams do not wait for
+    HIPCHK(ctx, hipMemsetAsync(ctx->wide.wtag, 0, wb, fs));
+    HIPCHK(ctx, hipMemsetAsync(ctx->wide.wlo, 0, wb, fs));
+    HIPCHK(ctx, hipMemsetAsync(ctx->wide.whi, 0, wb, fs));
+    HIPCHK(ctx, hipMemsetAsync(ctx->wide.wcount, 0, wb, fs));
+    HIPCHK(ctx, fallback_counters_clear(fs));
+    if (ctx->g1.counters) HIPCHK(ctx, hipMemsetAsync(ctx->g1.counters, 0, 16, fs));  // a new input: nothing is left in the stale map
+    if (int rc = order_behind_fills(ctx)) return rc;
     // the callers have synchronised every slot: no copy into h_seen is in flight
     std::lock_guard<std::mutex> lk(ctx->seen_mu);
     for (auto &sl : ctx->slots) memset(sl.h_seen, 0, kDiagWords * 4);
@@ -929,7 +957,8 @@ extern "C" int trew_hip_table_pressure(trew_hip_ctx *ctx, uint64_t *used_slots, 
         }
         for (int i = 0; i < kDiagWords; i++) diag[i] = ctx->seen[i].load(std::memory_order_relaxed);
     } else {
-        // a plain blocking copy: a snapshot of monotonic counters, the slot streams are not waited for
+        // a plain blocking copy: a snapshot of monotonic counters, the slot streams are not waited for (a reset still in flight is)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->fill_stream));
         HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
     }
     const u32 n_spill = diag[kDiagSpillRows];
@@ -1005,13 +1034,29 @@ extern "C" int trew_hip_add_gathered_device(trew_hip_ctx *ctx, const trew_hip_ro
     return check_diag(ctx, diag);
 }
 
+extern "C" int trew_hip_debug_worklist(trew_hip_ctx *ctx, int slot, uint32_t *units, uint64_t cap, uint64_t *n) {
+    if (!ctx || !n) return -1;
+    if (slot < 0 || slot >= (int) ctx->slots.size()) return fail(ctx, "slot out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->p.device));
+    Slot &s = ctx->slots[(size_t) slot];
+    HIPCHK(ctx, hipStreamSynchronize(s.stream));
+    u32 c = 0;
+    // the counter block of the last launch keeps its worklist size: the NEXT launch's exact kernel clears it (see exact_kernel)
+    if (s.n_launches) HIPCHK(ctx, hipMemcpy(&c, s.d_wl_count + ((s.n_launches - 1) & 1) * kWlCountWords, 4, hipMemcpyDeviceToHost));
+    c = (u32) std::min<u64>(c, ctx->p.max_batch_reads);
+    *n = c;
+    const u64 take = std::min<u64>(c, cap);
+    if (units && take) HIPCHK(ctx, hipMemcpy(units, s.d_wl, take * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int trew_hip_debug_counters(trew_hip_ctx *ctx, uint64_t *out, int n) {
     if (!ctx || !out || n < 0) return -1;
     if (int rc = sync_all(ctx)) return rc;
     u32 diag[kDiagWords], fb[kFallbackWords];
     HIPCHK(ctx, hipMemcpy(diag, ctx->table.overflow, sizeof(diag), hipMemcpyDeviceToHost));
     HIPCHK(ctx, fallback_counters_read(fb));
-    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide], fb[kFallbackGroupPunt], fb[kFallbackGroupRouted], fb[kFallbackGroupTarget], fb[6], fb[7]};
+    const u32 v[TREW_DEBUG_COUNTERS] = {fb[kFallbackStrictRerun], fb[kFallbackWindows], fb[kFallbackWideSpin], diag[kDiagInserted], diag[kDiagInsertedWide], fb[kFallbackGroupPunt], fb[kFallbackGroupRouted], fb[kFallbackGroupTarget]};
     for (int i = 0; i < n; i++) out[i] = i < TREW_DEBUG_COUNTERS ? v[i] : 0;
     return 0;
 }

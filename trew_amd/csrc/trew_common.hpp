@@ -52,7 +52,7 @@ enum {
     kDiagIntentDrop = 2,   // the pair driver logged more than 32 deferred emissions for one pair (cannot happen: <= 20)
     kDiagInserted = 3,     // keys inserted into the narrow table (occupancy, trew_hip_table_pressure)
     kDiagInsertedWide = 4, // keys inserted into the wide table
-    kDiagBadRow = 5,       // unused since ABI 3 (rows are validated in a pass of their own, see kRowFlag*)
+    kDiagKernarg = 5,      // TREW_FLAG_DEBUG_POISON_LDS runs: the table descriptor read through the kernarg pointer differed from the by-value argument
     kDiagSpillRows = 6,    // rows in the spill log (DevWide::spill_n points here: one copy reads the whole fill state)
     kDiagG1Drop = 7,       // TREW_FLAG_COMPAT_G1: the stale-row log or its carry was full (collect fails)
     kDiagWords = 16
@@ -85,7 +85,7 @@ struct DevTable {
 // TREW_FLAG_COMPAT_G1 (pair mode): what the whole-read block of a pair recorded into temp_result_left stays there in the
 // reference's 64-bit branch and is added again by the next pair.  The exact kernel logs those rows and every pair's
 // chain flags; g1_apply_kernel adds them again after the batch's exact kernel, rows of the batch's last pair travel to the next
-// batch in a carry buffer.  Lives behind the DevTable in the context's device-resident descriptor (DevTableG1).
+// batch in a carry buffer.  Lives behind the DevTable in the exact kernels' descriptor argument (DevTableG1, defined below DevWide).
 struct DevG1 {
     trew_hip_row *log;          // {k, table = forward_high | forward_low, word_lo, word_hi = pair index in the batch, count}
     u32 *counters;              // [0] rows in log, [1] rows in the carry read by this batch, [2] rows in the carry it writes
@@ -93,10 +93,7 @@ struct DevG1 {
                                 // bit 2 + b = the whole-read block's `both` condition (kmer.cpp:487, 494); zeroed per batch
     u32 log_cap;
 };
-struct DevTableG1 {
-    DevTable t;
-    DevG1 g;
-};
+
 
 // wide entries (k in (32, 64], 128-bit words): tag / word halves / count per slot.  Kept behind a
 // pointer so that DevTable stays small enough to travel in registers.
@@ -110,6 +107,12 @@ struct DevWide {
     trew_hip_row *spill_rows;
     u32 *spill_n;
     u32 spin_limit;  // polls of a claimed slot's ready bit before table_add_wide gives up on it (0 with TREW_FLAG_DEBUG_WIDE_NO_WAIT)
+};
+
+struct DevTableG1 {
+    DevTable t;
+    DevG1 g;
+    DevWide w;  // the wide-table descriptor by value as well: the exact kernels read it where t.wide would point (load_table)
 };
 
 // per-read outputs of TREW_MODE_SEGMENT

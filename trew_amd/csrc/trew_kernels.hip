@@ -154,9 +154,10 @@ hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevPar
 }
 
 hipError_t fallback_counters_read(u32 *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fallback), sizeof(u32) * kFallbackWords); }
-hipError_t fallback_counters_clear() {
-    const u32 z[kFallbackWords] = {0, 0, 0, 0, 0, 0, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_fallback), z, sizeof(z));
+hipError_t fallback_counters_clear(hipStream_t st) {  // in stream order
+    void *p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_fallback));
+    return e != hipSuccess ? e : hipMemsetAsync(p, 0, sizeof(u32) * kFallbackWords, st);
 }
 
 u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes) { return exact_lds_bytes(cap, rawwords, wordbytes); }

@@ -18,7 +18,7 @@ u32 exact_lds_bytes_host(u32 cap, u32 rawwords, u32 wordbytes);
 hipError_t launch_g1_apply(hipStream_t st, const DevTable &T, const DevG1 &G, const DevBatch &B, int min_mer, const trew_hip_row *carry_in,
                            trew_hip_row *carry_out, u32 carry_cap);
 hipError_t fallback_counters_read(u32 *out);  // kFallbackWords words of the current device
-hipError_t fallback_counters_clear();
+hipError_t fallback_counters_clear(hipStream_t st);  // queued on st
 hipError_t launch_add_rows(hipStream_t st, const DevTable &T, const trew_hip_row *d_rows, u64 n, u32 *d_flags);
 hipError_t launch_add_gathered(hipStream_t st, const DevTable &T, const trew_hip_row *d_buf, u32 n_slices, u32 own, u64 slice_rows, u32 *d_flags);
 hipError_t launch_pack_ascii(hipStream_t st, const unsigned char *d_bases, const u32 *d_byte_offsets, const u32 *d_lengths, const u32 *d_word_offsets,
