@@ -228,7 +228,9 @@ hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &
     // keeps both resident from start to end (measured, 10 M reads a step, two streams: 1.048 -> 0.989 ms; pair mode
     // 11.14 -> 11.04 ms; long reads, where the prefilter is a quarter of the work, are better off with the whole chip:
     // 3.60 against 3.69 ms -- profiles/r03/README.md).
-    if (share && P.mode != TREW_MODE_LONG) per_cu = std::max(1, per_cu / 2);
+    // Round 4: with the pair kernel a third shorter the split stopped paying there too (50 M pairs: 11.15 ms a step with half the
+    // slots, 9.44 with all of them, 9.38 on one stream -- the kernels of the two slots run one after the other either way).
+    if (share && P.mode == TREW_MODE_SHORT) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("TREW_EXACT_WAVES_PER_CU")) per_cu = std::max(1, atoi(e));  // experiments only
     // Self-scheduling waves: any grid size is correct, it only has to be large enough to keep the chip busy.  A big
     // batch gets every resident wave slot; a small one (the CLI's ~10^5-read batches, of which 1-2 % survive the
