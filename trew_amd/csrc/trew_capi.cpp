@@ -85,7 +85,10 @@ struct trew_hip_ctx {
     // (2 us for 256 MiB, tools/memset_probe.hip) while the fill takes 0.13 ms, and the slots' non-blocking streams do not wait for
     // the null stream: a batch submitted right behind it scanned into a table that was still being cleared (round 3's "empty
     // tables once in 270 runs").  Stream order instead of a host wait: init / reset do not stall the submitting threads.
-    hipStream_t fill_stream = nullptr;
+    // (The fill stream IS the copy stream: a stream of its own changed which hardware queue the slots' streams landed on -- ROCm
+    // spreads a process's streams over four queues in creation order -- and the two batch slots of bench.py stopped overlapping:
+    // 1.10 ms a step instead of 0.91.  Fills only happen while no batch copy is in flight.)
+    hipStream_t fill_stream = nullptr;  // alias of copy_stream
     hipEvent_t ev_filled = nullptr;
     int n_cu = 256;
     // persistent scratch of trew_hip_collect (device-side compaction)
@@ -170,7 +173,6 @@ static float conservative_lowf(double low) {
 // an event behind everything queued on the fill stream so far; the copy stream and every slot's stream wait for it on the device
 static int order_behind_fills(trew_hip_ctx *ctx) {
     HIPCHK(ctx, hipEventRecord(ctx->ev_filled, ctx->fill_stream));
-    if (ctx->copy_stream) HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_filled, 0));
     for (auto &s : ctx->slots)
         if (s.stream) HIPCHK(ctx, hipStreamWaitEvent(s.stream, ctx->ev_filled, 0));
     return 0;
@@ -233,7 +235,8 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
         trew_hip_destroy(ctx);
         return -3;
     };
-    if ((e = hipStreamCreateWithFlags(&ctx->fill_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    ctx->fill_stream = ctx->copy_stream;
     if ((e = hipEventCreateWithFlags(&ctx->ev_filled, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     ctx->table_slots = 1ull << p.table_log2_slots;
     ctx->table.log2_part_slots = p.table_log2_slots - kTablePartBits;
@@ -285,7 +288,6 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
 
     if ((e = hipMalloc((void **) &ctx->d_row_flags, kRowFlagWords * 4)) != hipSuccess) return bail("hipMalloc(row flags)", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_producer, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     ctx->slots.resize((size_t) p.n_slots);
     for (auto &s : ctx->slots) {
         if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -357,9 +359,8 @@ extern "C" void trew_hip_destroy(trew_hip_ctx *ctx) {
         if (s.ev_copied) (void) hipEventDestroy(s.ev_copied);
         if (s.stream) (void) hipStreamDestroy(s.stream);
     }
-    if (ctx->fill_stream) (void) hipStreamSynchronize(ctx->fill_stream);
+    if (ctx->copy_stream) (void) hipStreamSynchronize(ctx->copy_stream);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
-    if (ctx->fill_stream) (void) hipStreamDestroy(ctx->fill_stream);
     if (ctx->ev_filled) (void) hipEventDestroy(ctx->ev_filled);
     if (ctx->table.keys) (void) hipFree(ctx->table.keys);
     if (ctx->table.counts) (void) hipFree(ctx->table.counts);
