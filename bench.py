@@ -125,8 +125,23 @@ def committed_profile(n, L):
                 "waves_resident_avg_per_simd": round(c["SQ_WAVE_CYCLES"] * 4.0 / simd_cycles, 2) if "SQ_WAVE_CYCLES" in c else None,
             }
             h = hot.get(kern)
-            if h:
-                share = h["half_rate_share_of_valu_insts"]
+            dyn = None
+            if kern == "exact_kernel":  # the exact kernel has no dominant loop: its mix is the DYNAMIC one of tools/region_mix.py
+                try:
+                    dyn = json.load(open(os.path.join(prof, "exact_dynamic_mix.json")))
+                except (OSError, ValueError):
+                    dyn = None
+            if dyn:
+                share = dyn["dynamic"]["half_rate_share_of_valu_insts"]
+                mix_from = ("dynamic: static class counts of every TREW_MARK region x the region's trips on the GPU (tools/region_mix.py, "
+                            "profiles/%s/exact_dynamic_mix.json: the regions' straight-line counts x trips model %.0f M VALU instructions against the %.0f M "
+                            "the counter saw -- both sides of wave-uniform branches are counted -- so only the class SHARE is taken from it), every opcode "
+                            "priced by tools/valu_rate.hip's measurement" % (rnd, dyn["dynamic"]["valu_insts_in_regions"] / 1e6, c["SQ_INSTS_VALU"] / 1e6))
+            elif h:
+                share, mix_from = h["half_rate_share_of_valu_insts"], "static: " + h["from"]
+            else:
+                share = None
+            if share is not None:
                 half = c["SQ_INSTS_VALU"] * share * c_half / simd_cycles
                 full = c["SQ_INSTS_VALU"] * (1.0 - share) * c_full / simd_cycles
                 entry["class_weighted"] = {
@@ -136,7 +151,8 @@ def committed_profile(n, L):
                     "valu_issue": round(half + full, 3),
                     "not_valu_issue": round(1.0 - half - full, 3),
                     "salu_per_valu_inst": round(c.get("SQ_INSTS_SALU", 0) / c["SQ_INSTS_VALU"], 3),
-                    "mix_from": h["from"],
+                    "lanes_per_valu_inst": round(c["SQ_THREAD_CYCLES_VALU"] / c["SQ_INSTS_VALU"], 1) if "SQ_THREAD_CYCLES_VALU" in c else None,
+                    "mix_from": mix_from,
                 }
             valu[kern] = entry
         valu["cycles_per_wave_inst"] = {"full_rate": c_full, "half_rate": c_half}
@@ -482,7 +498,8 @@ def main():
         traffic_all, valu, prof_round = (None, None, None)
         if args.mode == "short" and args.min_mer == 5 and args.max_mer == 32:
             traffic_all, valu, prof_round = committed_profile(n, L)
-        traffic = traffic_all.get(dom) if traffic_all else None
+        # counter traffic of one STEP (both kernels of a slot; FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md), with the split
+        traffic = round(sum(traffic_all.values())) if traffic_all else None
         s_f, s_e = m["serial_ms"]
         s_dom = s_f if dom == "filter_kernel" else s_e
         workload = workload_name(args.mode, n, w.bases_per_step)
@@ -519,16 +536,20 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_by_kernel": traffic_all,
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "avg_launch_ms": {"filter_kernel": round(f_avg, 4), "exact_kernel": round(e_avg, 4)},
                 "slot_cycle_ms": round(f_avg + e_avg, 4),  # one slot runs its prefilter then its exact kernel: with S slots a step takes >= slot_cycle_ms / S
                 "serial_launch_ms": {"filter_kernel": round(s_f, 4), "exact_kernel": round(s_e, 4)},
                 "frac_serial": round(alg_bytes / (s_dom * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "valu": valu,
-                "valu_busy": ((valu or {}).get(dom, {}).get("class_weighted") or {}).get("valu_issue"),
+                # MODELLED, not a counter: SQ_INSTS_VALU of the committed profile x the measured cost of its instruction classes
+                "valu_issue_modelled": ((valu or {}).get(dom, {}).get("class_weighted") or {}).get("valu_issue"),
                 "note": "integer-issue bound, not HBM bound (SURVEY 8(d)). avg_launch_ms: HIP events over the timed region, where the %d slots overlap "
                         "(a kernel shares the SIMDs with the other slot's kernel, so its own launch is longer than alone); serial_launch_ms: the same "
-                        "kernels alone on one stream, measured in this run outside the timed region.  valu: SQ counters of the committed rocprofv3 PMC "
-                        "runs of this command (profiles/%s): issue_frac_2cyc = SQ_INSTS_VALU x 2 / SIMD cycles, class_weighted = the same with the measured cost of full-rate (2.26 cycles) and half-rate (4.15 cycles) instructions, see bench.py::committed_profile.  %.3g (window,k) "
+                        "kernels alone on one stream, measured in this run outside the timed region.  traffic: HBM bytes of one step from the committed PMC runs "
+                        "(both kernels; achieved / frac use the ALGORITHMIC bytes).  valu: SQ counters of the committed rocprofv3 PMC "
+                        "runs of this command (profiles/%s): issue_frac_2cyc = SQ_INSTS_VALU x 2 / SIMD cycles, class_weighted = the same with the measured cost of full-rate and half-rate instructions (profiles/valu_rate.json) -- the prefilter's mix is the static one of its dominant loop, the exact kernel's the dynamic one of tools/region_mix.py; see bench.py::committed_profile.  %.3g (window,k) "
                         "evals/s = %.3f of the %.3g lane-op/s VALU peak at 1 lane-op per eval"
                         % (max(1, args.streams), prof_round or "none for this configuration", evals / (ms_per_step * 1e-3),
                            evals / (ms_per_step * 1e-3) / VALU_PEAK_LANEOPS, VALU_PEAK_LANEOPS),

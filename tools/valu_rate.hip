@@ -54,17 +54,31 @@
 #define OP_MULLO(a, b) "v_mul_lo_u32 " a ", " b ", " a "\n"
 #define OP_SAD(a, b) "v_sad_u8 " a ", " a ", " b ", " a "\n"
 #define OP_DOT4(a, b) "v_dot4_u32_u8 " a ", " a ", " b ", " a "\n"
+// round 4: the cross-lane and select ops the exact kernel is full of (scalar destinations s20..s27 are clobbered)
+#define OP_MAXU(a, b) "v_max_u32 " a ", " b ", " a "\n"
+#define OP_MINU(a, b) "v_min_u32 " a ", " b ", " a "\n"
+#define OP_OR(a, b) "v_or_b32 " a ", " b ", " a "\n"
+#define OP_LSHL32(a, b) "v_lshlrev_b32 " a ", %8, " a "\n"
+#define OP_MUL24(a, b) "v_mul_u32_u24 " a ", " b ", " a "\n"
+#define OP_DPPMOV(a, b) "v_mov_b32_dpp " a ", " b " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define OP_DPPOR(a, b) "v_or_b32_dpp " a ", " b ", " a " row_ror:4 row_mask:0xf bank_mask:0xf\n"
+#define OP_WRITELANE(a, b) "v_writelane_b32 " a ", %8, 3\n"
+#define OP_CMPEQ(a, b) "v_cmp_eq_u32 vcc, " a ", " b "\n"
+#define OP_CMP64(a, b) "v_cmp_lt_u64 vcc, " a ", " b "\n"
 
-enum { N_OPS = 26 };
+enum { N_OPS = 38 };
 static const char *kNames[N_OPS] = {"v_xor_b32",     "v_alignbit_b32", "v_bcnt_u32_b32", "v_bitop3_b32",  "v_add_u32",      "v_lshrrev_b32", "v_lshl_or_b32",
                                     "v_max3_u32",    "v_sub_u32",      "v_and_b32",      "v_bfe_u32",     "v_perm_b32",     "v_cmp_le_u32",  "v_mov_b32",
                                     "v_lshrrev_b64", "v_lshlrev_b64",  "v_mad_u64_u32",  "v_add_co_u32",  "v_cndmask_b32",  "v_mbcnt_lo",    "v_ffbl_b32",
-                                    "v_bfrev_b32",   "v_mul_lo_u32",   "v_sad_u8",       "v_dot4_u32_u8", "xor+alignbit+bcnt mix (the prefilter's k loop)"};
+                                    "v_bfrev_b32",   "v_mul_lo_u32",   "v_sad_u8",       "v_dot4_u32_u8", "xor+alignbit+bcnt mix (the prefilter's k loop)",
+                                    "v_max_u32",     "v_min_u32",      "v_or_b32",       "v_lshlrev_b32", "v_mul_u32_u24",  "v_mov_b32_dpp", "v_or_b32_dpp",
+                                    "v_writelane_b32", "v_cmp_eq_u32", "v_cmp_lt_u64",   "v_readlane_b32", "v_readfirstlane_b32"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stamps, int iters, unsigned s) {
     unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 ^ 0x55, a5 = a0 + 9, a6 = a0 * 11, a7 = ~a0;
     unsigned long long b0 = a0 * 0x9E3779B97F4A7C15ull, b1 = b0 * 3, b2 = b0 * 5, b3 = b0 * 7, b4 = ~b0, b5 = b0 + 9, b6 = b0 * 11, b7 = b0 ^ 0x5555;
+    asm volatile("s_mov_b64 s[20:21], 0x55555555" ::: "s20", "s21");  // select mask of the v_cndmask test
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
         if (OP == 0) { REP8(CHAIN8(OP_XOR);) }
@@ -85,13 +99,45 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stam
         if (OP == 15) { REP8(CHAIN8_64(OP_LSHL64);) }
         if (OP == 16) { REP8(asm volatile(OP_MADU64("%0", "%1") OP_MADU64("%0", "%2") OP_MADU64("%0", "%1") OP_MADU64("%0", "%2") OP_MADU64("%3", "%1") OP_MADU64("%3", "%2") OP_MADU64("%3", "%1") OP_MADU64("%3", "%2") : "+v"(b0), "+v"(a1), "+v"(a2), "+v"(b3) : : "vcc");) }
         if (OP == 17) { REP8(CHAIN8(OP_ADDC);) }
-        if (OP == 18) { REP8(CHAIN8(OP_CNDMASK);) }
+        if (OP == 18) {
+            // the select mask in an SGPR pair set once (with vcc, which nothing here writes, the first version measured 22.8 cycles)
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]\n v_cndmask_b32_e64 %2, %2, %3, s[20:21]\n"
+                              "v_cndmask_b32_e64 %3, %3, %4, s[20:21]\n v_cndmask_b32_e64 %4, %4, %5, s[20:21]\n v_cndmask_b32_e64 %5, %5, %6, s[20:21]\n"
+                              "v_cndmask_b32_e64 %6, %6, %7, s[20:21]\n v_cndmask_b32_e64 %7, %7, %0, s[20:21]\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                              : "s"(s)
+                              : "s20", "s21");)
+        }
         if (OP == 19) { REP8(CHAIN8(OP_MBCNT);) }
         if (OP == 20) { REP8(CHAIN8(OP_FFBL);) }
         if (OP == 21) { REP8(CHAIN8(OP_BFREV);) }
         if (OP == 22) { REP8(CHAIN8(OP_MULLO);) }
         if (OP == 23) { REP8(CHAIN8(OP_SAD);) }
         if (OP == 24) { REP8(CHAIN8(OP_DOT4);) }
+        if (OP == 26) { REP8(CHAIN8(OP_MAXU);) }
+        if (OP == 27) { REP8(CHAIN8(OP_MINU);) }
+        if (OP == 28) { REP8(CHAIN8(OP_OR);) }
+        if (OP == 29) { REP8(CHAIN8(OP_LSHL32);) }
+        if (OP == 30) { REP8(CHAIN8(OP_MUL24);) }
+        if (OP == 31) { REP8(CHAIN8(OP_DPPMOV);) }
+        if (OP == 32) { REP8(CHAIN8(OP_DPPOR);) }
+        if (OP == 33) { REP8(CHAIN8(OP_WRITELANE);) }
+        if (OP == 34) { REP8(CHAIN8(OP_CMPEQ);) }
+        if (OP == 35) { REP8(CHAIN8_64(OP_CMP64);) }
+        if (OP == 36) {
+            REP8(asm volatile("v_readlane_b32 s20, %0, 1\n v_readlane_b32 s21, %1, 2\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 4\n"
+                              "v_readlane_b32 s24, %4, 5\n v_readlane_b32 s25, %5, 6\n v_readlane_b32 s26, %6, 7\n v_readlane_b32 s27, %7, 8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                              : "s"(s)
+                              : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        }
+        if (OP == 37) {
+            REP8(asm volatile("v_readfirstlane_b32 s20, %0\n v_readfirstlane_b32 s21, %1\n v_readfirstlane_b32 s22, %2\n v_readfirstlane_b32 s23, %3\n"
+                              "v_readfirstlane_b32 s24, %4\n v_readfirstlane_b32 s25, %5\n v_readfirstlane_b32 s26, %6\n v_readfirstlane_b32 s27, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                              : "s"(s)
+                              : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        }
         if (OP == 25) {
             // the instruction mix of one (k, word) of the prefilter's fast path: 2 alignbit, 2 xor, 1 and, 3 bcnt
             REP8(asm volatile("v_alignbit_b32 %4, %1, %0, %8\n v_alignbit_b32 %5, %3, %2, %8\n v_xor_b32 %4, %4, %0\n v_xor_b32 %5, %5, %2\n"
