@@ -305,6 +305,77 @@ def test_cli_bgzf_input(tmp_path):
     assert run("short", "5", "32", "--paired_end", "--fq1", z1, "--fq2", z2, "-t", "4") == want_pair
 
 
+@pytest.mark.parametrize("block", [0xFF00, 4000, 777])
+def test_cli_bgzf_block_parallel_reader(tmp_path, block):
+    """BGZF input, single file: members are indexed from their headers, worker threads inflate groups of them into place and
+    locate the sequence lines there (run_blocks_bgzf) -- the same CSV as the plain file through the block reader and as the same
+    BGZF file through the serial reader, with members of 64 KiB, 4 000 and 777 bytes (lines and records span members and
+    blocks), CRLF line ends, reads of unequal length, and in long mode."""
+    from helpers import periodic
+    from test_bgzf_cpu import write_bgzf
+
+    import random
+
+    rnd = random.Random(31 + block)
+    buf, st, nd = capi.synth_short_ascii(20250218, 100, 60000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    reads += [periodic("TTAGGG", rnd.randint(20, 900), rnd.randint(0, 5)).encode() for _ in range(400)] + [b"", b"ACGT"]
+    rnd.shuffle(reads)
+    plain, z = str(tmp_path / "r.fastq"), str(tmp_path / "r.fastq.gz")
+    write_fastq(plain, reads, crlf=(block == 4000))
+    write_bgzf(z, open(plain, "rb").read(), block=block)
+    if block == 4000:  # CRLF: the carriage return is part of the sequence line, as in the reference
+        reads = [r + b"\r" for r in reads]
+    want = expected([(z, O.run_short(O.OracleParams(), reads))], 5)
+    r = subprocess.run([TREW, "short", "5", "32", z, "-t", "5", "--stats"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "block-parallel BGZF reader" in r.stderr
+    assert r.stdout.splitlines() == want
+    assert run("short", "5", "32", z, "-t", "5", "--serial_reader") == want
+    assert run("short", "5", "32", z, "-t", "3", "--host_pack", "--batch_mib", "1") == want
+
+
+def test_cli_bgzf_block_parallel_long_reads_and_fallbacks(tmp_path):
+    """Long reads (lines of tens of kilobases across many members and across blocks) through the BGZF block reader; a file that
+    is BGZF followed by a plain gzip member, and a BGZF file with a damaged member, take the serial reader's way (same
+    output / same error)."""
+    import gzip as gz
+
+    from test_bgzf_cpu import write_bgzf
+    from test_gpu_parity import _long_reads
+
+    lr = [r for r in _long_reads(11, 150) if len(r) >= 150]
+    plain, z = str(tmp_path / "l.fastq"), str(tmp_path / "l.fastq.gz")
+    write_fastq(plain, lr)
+    write_bgzf(z, open(plain, "rb").read(), block=30000)
+    want = expected([(z, O.run_long(O.OracleParams(slice_len=150), lr))], 5)
+    r = subprocess.run([TREW, "long", "5", "32", z, "-t", "4", "--stats"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "block-parallel BGZF reader" in r.stderr, r.stderr
+    assert r.stdout.splitlines() == want
+    # BGZF + a plain gzip member: not BGZF from end to end -> serial reader, which reads both parts (as gzread does)
+    buf, st, nd = capi.synth_short_ascii(20250218, 0, 6000, 150)
+    reads = [buf[s:e + 1] for s, e in zip(st, nd)]
+    pa, pb, mixed = str(tmp_path / "a.fastq"), str(tmp_path / "b.fastq"), str(tmp_path / "mixed.fastq.gz")
+    write_fastq(pa, reads[:3000])
+    write_fastq(pb, reads[3000:])
+    za = str(tmp_path / "a.gz")
+    write_bgzf(za, open(pa, "rb").read(), block=5000)
+    data = open(za, "rb").read()
+    data = data[:-28] if data.endswith(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")) else data  # drop the empty EOF member if there is one
+    open(mixed, "wb").write(data + gz.compress(open(pb, "rb").read()))
+    want = expected([(mixed, O.run_short(O.OracleParams(), reads))], 5)
+    r = subprocess.run([TREW, "short", "5", "32", mixed, "-t", "4", "--stats"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "serial reader" in r.stderr, r.stderr
+    assert r.stdout.splitlines() == want
+    # a damaged member (a byte of its deflate stream flipped): an error either way, never a silent difference
+    bad = bytearray(open(za, "rb").read())
+    bad[len(bad) // 2] ^= 0x5A
+    pbad = str(tmp_path / "bad.fastq.gz")
+    open(pbad, "wb").write(bytes(bad))
+    r = subprocess.run([TREW, "short", "5", "32", pbad, "-t", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "Error" in r.stderr
+
+
 def _rank_scan(rank, world, port, n, q):
     import torch.distributed as dist
 

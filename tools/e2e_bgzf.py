@@ -63,6 +63,11 @@ def main():
             r = subprocess.run([trew, "short", "5", "32", gz, "-t", "16", "--stats"], capture_output=True, text=True)
             m = re.search(r"([0-9.]+) s, ([0-9.]+) Gbases/s end-to-end", r.stderr)
             print("trew -t 16:", m.group(0) if m else r.stderr[-300:])
+            if rep == 1:
+                print(r.stderr[-1500:])
+        r = subprocess.run([trew, "short", "5", "32", gz, "-t", "16", "--stats", "--serial_reader"], capture_output=True, text=True)
+        m = re.search(r"([0-9.]+) s, ([0-9.]+) Gbases/s end-to-end", r.stderr)
+        print("trew -t 16 --serial_reader:", m.group(0) if m else r.stderr[-300:])
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)

@@ -272,4 +272,94 @@ private:
     size_t cur_pos_ = 0;
 };
 
+// ------------------------------------------------------------------ BGZF as random-access text (round 4)
+// Every BGZF member says how long it is compressed ('BC' subfield) and uncompressed (ISIZE, its last four bytes), so one
+// cheap walk over the headers of the mapped file gives the position of every member's text in the decompressed stream without
+// inflating anything.  The block-parallel FASTQ reader (fastq_blocks.hpp, process.cpp) then treats the decompressed stream as
+// a file it can address: worker threads claim groups of consecutive members ("blocks" of ~4 MiB of text), inflate them straight
+// into their place in a reserved address range and locate the sequence lines there -- no serial reader thread any more.
+struct BgzfIndex {
+    struct Member {
+        uint64_t coff;   // offset of the member in the file
+        uint32_t csize;  // its size there
+        uint32_t hsize;  // of which header (the deflate stream starts behind it)
+        uint32_t isize;  // uncompressed size
+        uint64_t toff;   // offset of its text in the decompressed stream
+    };
+    std::vector<Member> members;
+    uint64_t text_size = 0;
+
+    // false (with a reason) when the file is not BGZF from end to end -- a plain gzip member, trailing bytes, a truncated or
+    // implausible member: the caller takes the serial reader, which handles (or reports) all of these as before
+    bool build(const unsigned char *p, size_t n, std::string *why) {
+        members.clear();
+        text_size = 0;
+        size_t at = 0;
+        while (at < n) {
+            if (n - at < 18 || p[at] != 0x1f || p[at + 1] != 0x8b || p[at + 2] != 8 || !(p[at + 3] & 4)) {
+                *why = "a member without the BGZF extra field";
+                return false;
+            }
+            if (p[at + 3] & ~4u) {  // FNAME / FCOMMENT / FHCRC: legal gzip, never written by bgzip
+                *why = "a member with optional gzip header fields";
+                return false;
+            }
+            const size_t xlen = (size_t) p[at + 10] | ((size_t) p[at + 11] << 8);
+            if (at + 12 + xlen > n) {
+                *why = "truncated member header";
+                return false;
+            }
+            size_t bsize = 0;
+            for (size_t q = at + 12; q + 4 <= at + 12 + xlen;) {
+                const size_t slen = (size_t) p[q + 2] | ((size_t) p[q + 3] << 8);
+                if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= at + 12 + xlen) bsize = ((size_t) p[q + 4] | ((size_t) p[q + 5] << 8)) + 1;
+                q += 4 + slen;
+            }
+            if (bsize == 0) {
+                *why = "a member without the BC subfield";
+                return false;
+            }
+            if (bsize < 12 + xlen + 8 || at + bsize > n) {
+                *why = "truncated or corrupt member";
+                return false;
+            }
+            const unsigned char *t = p + at + bsize - 4;
+            const uint32_t isize = (uint32_t) t[0] | ((uint32_t) t[1] << 8) | ((uint32_t) t[2] << 16) | ((uint32_t) t[3] << 24);
+            if (isize > 65536u) {
+                *why = "a member with more than 64 KiB of text";
+                return false;
+            }
+            Member m;
+            m.coff = at;
+            m.csize = (uint32_t) bsize;
+            m.hsize = (uint32_t) (12 + xlen);
+            m.isize = isize;
+            m.toff = text_size;
+            members.push_back(m);
+            text_size += isize;
+            at += bsize;
+        }
+        return true;
+    }
+
+    // inflates member i into dst (isize bytes), checking length and CRC as BgzfReader does; false on a data error
+    bool inflate_member(const unsigned char *file, size_t i, unsigned char *dst) const {
+        const Member &m = members[i];
+        if (m.isize == 0) return true;
+        const unsigned char *c = file + m.coff;
+        const uint32_t crc = (uint32_t) c[m.csize - 8] | ((uint32_t) c[m.csize - 7] << 8) | ((uint32_t) c[m.csize - 6] << 16) | ((uint32_t) c[m.csize - 5] << 24);
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<unsigned char *>(c + m.hsize);
+        zs.avail_in = (uInt) (m.csize - m.hsize - 8);
+        zs.next_out = dst;
+        zs.avail_out = m.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        const bool ok = rc == Z_STREAM_END && zs.total_out == m.isize;
+        inflateEnd(&zs);
+        return ok && (uint32_t) crc32(crc32(0L, Z_NULL, 0), dst, m.isize) == crc;
+    }
+};
+
 }  // namespace trew_host

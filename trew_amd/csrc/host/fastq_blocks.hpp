@@ -12,8 +12,10 @@
 
 #include <atomic>
 #include <cstdint>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -175,6 +177,12 @@ struct LineIndex {
 struct BlockScan {
     const char *base = nullptr;
     size_t size = 0, block = 0, n_blocks = 0;
+    // blocks of unequal size (BGZF input: a block is a group of members): block b = [bounds[b], bounds[b+1]); empty = b * block.
+    // `block` is then the size of the largest one.
+    std::vector<size_t> bounds;
+    // called with the claimed block before it is scanned (BGZF input: inflate the block's members into [lo, hi)); may be empty
+    std::function<void(size_t b, size_t lo, size_t hi)> fill;
+    bool anonymous = false;  // base is anonymous memory: what release() drops is gone for good (see release)
     std::atomic<size_t> next{0};
     // published by the worker of block b once its predecessor's values are known:
     // lines_end[b] = newlines in [0, end of block b) (-1: not yet known);
@@ -183,10 +191,22 @@ struct BlockScan {
     std::unique_ptr<int64_t[]> last_nl;
     bool populate = false;  // base is a page-aligned file mapping: pre-fault each block when it is claimed
 
+    // (call init_bounds instead for blocks of unequal size)
+    void init_bounds(const char *base_, size_t size_, std::vector<size_t> bounds_) {
+        size_t big = 1;
+        for (size_t i = 0; i + 1 < bounds_.size(); i++) big = std::max(big, bounds_[i + 1] - bounds_[i]);
+        init(base_, size_, big);
+        bounds = std::move(bounds_);
+        n_blocks = bounds.size() - 1;
+        lines_end.reset(new std::atomic<int64_t>[n_blocks ? n_blocks : 1]);
+        last_nl.reset(new int64_t[n_blocks ? n_blocks : 1]);
+        for (size_t i = 0; i < n_blocks; i++) lines_end[i].store(-1, std::memory_order_relaxed);
+    }
     void init(const char *base_, size_t size_, size_t block_) {
         base = base_;
         size = size_;
         block = block_;
+        bounds.clear();
         n_blocks = (size + block - 1) / block;
         lines_end.reset(new std::atomic<int64_t>[n_blocks]);
         last_nl.reset(new int64_t[n_blocks]);
@@ -202,7 +222,8 @@ struct BlockScan {
         if (b >= n_blocks) return false;
         if (claimed) *claimed = b;
         if (nl.size() < block + 2) nl.resize(block + 2);
-        const size_t lo = b * block, hi = lo + block < size ? lo + block : size;
+        const size_t lo = bounds.empty() ? b * block : bounds[b], hi = bounds.empty() ? (lo + block < size ? lo + block : size) : bounds[b + 1];
+        if (fill) fill(b, lo, hi);
         if (populate) {
             // map the block's pages with one call instead of a page fault per 64 KiB of a cold mapping (Linux >= 5.14;
             // any failure just leaves the faults to happen)
@@ -240,9 +261,17 @@ struct BlockScan {
     // 4-KiB pages, single-threaded, measured); MADV_DONTNEED only takes the mapping's lock for reading, so the workers pay
     // for it in parallel, a block at a time.  A line that started in this block and ends in the next simply faults its
     // pages in again (they are still in the page cache).
+    // Anonymous memory (BGZF text) does not come back: there the pages from the block's last line start on are kept -- the next
+    // block reads the line that straddles the boundary from them -- and never given back (a page or two per block; with long
+    // reads up to a line's length, a few per cent of the text).
     void release(size_t b) const {
-        if (!populate || b >= n_blocks) return;
-        const size_t page = 4096, lo = b * block, hi = lo + block < size ? lo + block : size;
+        if ((!populate && !anonymous) || b >= n_blocks) return;
+        const size_t page = 4096, lo = bounds.empty() ? b * block : bounds[b];
+        size_t hi = bounds.empty() ? (lo + block < size ? lo + block : size) : bounds[b + 1];
+        if (anonymous) {
+            const int64_t ln = last_nl[b];
+            hi = ln >= 0 && (size_t) ln + 1 > lo ? (size_t) ln + 1 : lo;
+        }
         const size_t plo = (lo + page - 1) & ~(page - 1), phi = hi & ~(page - 1);
         if (phi > plo) (void) madvise(const_cast<char *>(base) + plo, phi - plo, MADV_DONTNEED);
     }

@@ -1025,6 +1025,65 @@ static bool run_blocks(Scanner *s, const char *name, bool long_mode, int slice_l
     return true;
 }
 
+// The same for block-gzip input (round 4): the decompressed stream is given an address range of its own (reserved, not
+// committed); a block is a group of consecutive members with ~4 MiB of text, and the worker that claims it inflates its
+// members into their place before it scans them (BlockScan::fill) -- inflate, newline scan, line copy and submit all run on the
+// workers, nothing is serial but the chain of line counts.  false when the file is not BGZF from end to end (a plain gzip
+// member, trailing bytes, a damaged member: the serial reader handles or reports those as before) or cannot be mapped.
+static bool run_blocks_bgzf(Scanner *s, const char *name, bool long_mode, int slice_length) {
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const clk::time_point t0 = clk::now();
+    {
+        Mapping m;
+        if (!m.map(name)) return false;
+        BgzfIndex idx;
+        std::string why;
+        if (!idx.build((const unsigned char *) m.p, m.size, &why)) return false;
+        if (idx.text_size == 0) return true;  // nothing in it
+        const size_t span = (size_t) idx.text_size + 8192;
+        void *text = mmap(nullptr, span, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (text == MAP_FAILED) return false;
+        std::vector<size_t> bounds, first_member;
+        size_t acc = 0;
+        for (size_t i = 0; i < idx.members.size(); i++) {
+            if (i == 0 || acc >= (size_t) LENGTH - 65536) {
+                bounds.push_back((size_t) idx.members[i].toff);
+                first_member.push_back(i);
+                acc = 0;
+            }
+            acc += idx.members[i].isize;
+        }
+        bounds.push_back((size_t) idx.text_size);
+        first_member.push_back(idx.members.size());
+        BlockJob job;
+        job.scan.init_bounds((const char *) text, (size_t) idx.text_size, bounds);
+        job.scan.anonymous = true;
+        job.scan.fill = [&](size_t b, size_t, size_t) {
+            for (size_t i = first_member[b]; i < first_member[b + 1]; i++)
+                if (!idx.inflate_member((const unsigned char *) m.p, i, (unsigned char *) text + idx.members[i].toff)) {
+                    fprintf(stderr, "File-IO Error: BGZF member fails to inflate (data error).\n");  // as the serial reader reports it (kmer.cpp:1021-1022)
+                    fflush(stdout);
+                    fflush(stderr);
+                    _exit(EXIT_FAILURE);
+                }
+        };
+        job.long_mode = long_mode;
+        job.slice_length = slice_length;
+        const clk::time_point t1 = clk::now();
+        std::vector<std::thread> th;
+        for (auto &w : s->workers) th.emplace_back(block_worker_loop, s, &w, &job);
+        for (auto &t : th) t.join();
+        const clk::time_point t2 = clk::now();
+        munmap(text, span);
+        s->t_map = secs(t0, t1);
+        s->t_workers = secs(t1, t2);
+        s->t_unmap = -secs(t0, t2);
+    }
+    s->t_unmap += secs(t0, clk::now());
+    return true;
+}
+
 // thread merge of process_output (kmer.cpp:1486-1515): what was drained during the file + what the devices
 // still hold.  With several devices the tables are first reduced on the GPUs (trew_hip_merge, one peer copy
 // per device) and only the merged rows cross PCIe.
@@ -1061,6 +1120,9 @@ static FinalFastqOutput run_file(Scanner *s, const Config &cfg, const char *name
     if (s->mode != TREW_MODE_PAIR && !gz1 && !cfg.serial_reader) {
         done = run_blocks(s, name1, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
         if (done) how = "block-parallel reader";
+    } else if (s->mode != TREW_MODE_PAIR && gz1 && !cfg.serial_reader && BgzfReader::sniff(name1)) {
+        done = run_blocks_bgzf(s, name1, s->mode == TREW_MODE_LONG, cfg.SLICE_LENGTH);
+        if (done) how = "block-parallel BGZF reader";
     } else if (s->mode == TREW_MODE_PAIR && !gz1 && !gz2 && !cfg.serial_reader) {
         done = run_pair_blocks(s, name1, name2);
         if (done) how = "block-parallel paired reader";
