@@ -619,7 +619,7 @@ def test_fuzz_all_modes(seed):
         assert t.collect() == want, ("long", kw, sl)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_GROUP_SEEDS", "12"))))
 def test_group_pass_matches_oracle_and_wave_per_segment(seed):
     """The exact kernel's group pass (four segments in lock step, 16 lanes each: decide_group, row-space routing, k_mer_target as
     a whole-read row count) only runs on batches whose halves fit 3- or 5-word masks, which the fuzz above (reads up to 1000
@@ -667,6 +667,97 @@ def test_group_pass_matches_oracle_and_wave_per_segment(seed):
                 assert c["group_punt"] == c["group_routed"] == c["group_target"] == 0, c  # the flag really turns the pass off
     assert got[0] == want, ("group pass", kw, maxlen, _table_diff(got[0], want))
     assert got[T.FLAG_DEBUG_NO_GROUP] == want, ("wave per segment", kw, maxlen)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_GROUP_SEEDS", "12"))))
+def test_group_pass_pairs_match_oracle_and_wave_per_segment(seed):
+    """The pair driver's group pass (the four half-read segments of a pair decided in lock step; a fully chained pair recorded
+    straight from the rows) on ragged batches of short pairs -- fragments that are repeats from end to end, repeats in one mate or
+    one half only, mates of unequal length, N, noise -- against the oracle and against TREW_FLAG_DEBUG_NO_GROUP."""
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(9100 + seed)
+    mn = rnd.choice([3, 4, 5, 5, 6, 9])
+    mx = max(mn, rnd.choice([mn, 12, 20, 31, 32, 32]))
+    low = rnd.choice([0.5, 0.5, 0.3, 0.51, 2 / 3, 0.75, 1.0])
+    high = max(low, rnd.choice([0.8, 0.6, 0.9, 0.9, 1.0]))
+    kw = dict(min_mer=mn, max_mer=mx, low=low, high=high)
+    maxlen = rnd.choice([150, 151, 200, 250, 300])
+    r1, r2 = [], []
+    for _ in range(900):
+        n1 = rnd.choice([maxlen, maxlen, rnd.randint(4 * mn, maxlen), rnd.randint(1, maxlen)])
+        n2 = n1 if rnd.random() < 0.7 else rnd.choice([maxlen, rnd.randint(1, maxlen)])
+        unit = "".join(rnd.choice("ACGT") for _ in range(rnd.choice([rnd.randint(1, 12), rnd.randint(1, 40), 6])))
+        frag = mutate(periodic(unit, n1 + n2, rnd.randint(0, 11)), rnd, p_sub=rnd.choice([0, 0.01, 0.01, 0.03, 0.08]), p_n=rnd.choice([0, 0, 0, 0.005, 0.02]))
+        kind = rnd.random()
+        if kind < 0.15:
+            frag = "".join(rnd.choice("ACGT") for _ in range(n1 + n2))
+        elif kind < 0.4:  # repeat in part of the fragment only
+            cut = rnd.choice([n1 // 2, n1, n1 + n2 // 2, rnd.randint(0, n1 + n2)])
+            rest = "".join(rnd.choice("ACGT") for _ in range(n1 + n2 - cut))
+            frag = frag[:cut] + rest if rnd.random() < 0.5 else rest + frag[:cut]
+        a = frag[:n1].encode()
+        b = frag[n1:n1 + n2].encode()
+        r1.append(a)
+        r2.append(_revcomp(b) if rnd.random() < 0.7 else b)
+    want = O.run_pair(O.OracleParams(**kw), r1, r2)
+    both = [x for pr in zip(r1, r2) for x in pr]
+    for flags in (0, T.FLAG_DEBUG_NO_GROUP):
+        with T.TrewHip(mode=T.MODE_PAIR, max_batch_reads=len(both) + 8, max_batch_words=1 << 22, flags=flags, **kw) as t:
+            t.submit_reads(both)
+            t.wait()
+            got = t.collect()
+        assert got == want, ("group pass" if not flags else "wave per segment", kw, maxlen, _table_diff(got, want))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TREW_GROUP_SEEDS", "12"))))
+def test_group_pass_long_reads_match_oracle_and_wave_per_slice(seed):
+    """The long driver with two reads per wave (run_long_groups: 32-lane groups, a slice per trip, records from registers, the
+    wave-per-slice code for the middle slice / groups that give up / reads that chain from end to end): reads with repeat tails
+    at either or both ends, reads that are one repeat from end to end (the forward chain runs through: forward -> both), noisy
+    ONT-like repeats, N, slice lengths up to 159 -- against the oracle and against TREW_FLAG_DEBUG_NO_GROUP."""
+    import random
+
+    from helpers import mutate, periodic
+
+    rnd = random.Random(5300 + seed)
+    mn = rnd.choice([3, 5, 5, 6, 9])
+    mx = max(mn, rnd.choice([12, 20, 31, 32, 32]))
+    sl = max(2 * mx, rnd.choice([64, 100, 128, 150, 150, 159]))
+    low = rnd.choice([0.5, 0.5, 0.3, 2 / 3, 0.75])
+    high = max(low, rnd.choice([0.8, 0.9, 0.9, 1.0]))
+    kw = dict(min_mer=mn, max_mer=mx, low=low, high=high)
+    reads = []
+    for _ in range(260):
+        n = rnd.choice([rnd.randint(sl, 3 * sl), rnd.randint(sl, 2500), rnd.randint(2000, 7000)])
+        body = "".join(rnd.choice("ACGT") for _ in range(n))
+        unit = rnd.choice(["TTAGGG", "CCCTAA", "TTAGGG", "TTTAGGG", "AT", "TTAGGGTTAGGC", "ACG", "".join(rnd.choice("ACGT") for _ in range(rnd.randint(2, 30)))])
+        psub = rnd.choice([0.0, 0.01, 0.03, 0.05, 0.05, 0.1])
+        pn = rnd.choice([0, 0, 0, 0.002, 0.01])
+        kind = rnd.random()
+        if kind < 0.3:  # 3' tail
+            t = min(n, rnd.randint(sl // 2, 3000))
+            body = body[: n - t] + mutate(periodic(unit, t, rnd.randint(0, 5)), rnd, p_sub=psub, p_n=pn)
+        elif kind < 0.55:  # 5' tail
+            t = min(n, rnd.randint(sl // 2, 3000))
+            body = mutate(periodic(unit, t, rnd.randint(0, 5)), rnd, p_sub=psub, p_n=pn) + body[t:]
+        elif kind < 0.75:  # one repeat from end to end
+            body = mutate(periodic(unit, n, rnd.randint(0, 5)), rnd, p_sub=rnd.choice([0.0, 0.01, 0.03]), p_n=rnd.choice([0, 0, 0.001]))
+        elif kind < 0.9:  # both ends, the same or different motifs
+            t = min(n // 2, rnd.randint(sl, 1500))
+            u2 = unit if rnd.random() < 0.5 else rnd.choice(["GGGTTA", "TTAGG", "CCCTAA"])
+            body = mutate(periodic(unit, t), rnd, p_sub=psub) + body[t: n - t] + mutate(periodic(u2, t), rnd, p_sub=psub)
+        reads.append(body[:n].encode())
+    want = O.run_long(O.OracleParams(slice_len=sl, **kw), reads)
+    assert sum(len(v) for v in want.values()) > 0
+    for flags in (0, T.FLAG_DEBUG_NO_GROUP):
+        with T.TrewHip(mode=T.MODE_LONG, slice_length=sl, max_batch_reads=len(reads) + 8, max_batch_words=1 << 22, flags=flags, **kw) as t:
+            t.submit_reads(reads)
+            t.wait()
+            got = t.collect()
+        assert got == want, ("two reads per wave" if not flags else "wave per slice", kw, sl, _table_diff(got, want))
 
 
 def test_group_pass_takes_almost_every_read_of_the_bench_workload():
