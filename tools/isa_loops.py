@@ -23,12 +23,26 @@ def load_classes():
     return set(r["classes"]["full_rate_ops"]), r["classes"]["full_rate"], r["classes"]["half_rate"]
 
 
-def classify(op, full):
+SCALAR_SRC = re.compile(r"^(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|ttmp\d+)$")
+
+
+def scalar_source(line):
+    """A VALU instruction that reads a scalar register occupies the SIMD like a half-rate one whatever its opcode
+    (tools/valu_rate.hip, the "(sgpr)" entries); inline constants and literals do not."""
+    t = line.split(";")[0].strip().split(None, 1)
+    if len(t) < 2:
+        return False
+    operands = [o.strip() for o in t[1].split(",")]
+    srcs = operands[2:] if re.match(r"v_(add|sub|subrev|addc|subb|subbrev)_co_u32|v_mad_u64_u32", t[0]) else operands[1:]
+    return any(SCALAR_SRC.match(o.split()[0]) for o in srcs if o)
+
+
+def classify(op, full, line=""):
     base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", op)
     if base.startswith("v_"):
         if base in ("v_readlane_b32", "v_readfirstlane_b32", "v_writelane_b32"):
             return "valu_lane"
-        return "valu_full" if base in full else "valu_half"
+        return "valu_full" if base in full and not scalar_source(line) else "valu_half"
     if base.startswith("s_load") or base.startswith("s_buffer_load"):
         return "smem"
     if base.startswith("s_cbranch") or base == "s_branch":
@@ -66,7 +80,7 @@ def tally(lines, full):
         t = ln.strip().split()
         if not t or t[0].startswith((".", ";", "/")) or t[0].endswith(":"):
             continue
-        cls = classify(t[0], full)
+        cls = classify(t[0], full, ln)
         c[cls] += 1
         if cls.startswith("valu"):
             ops[re.sub(r"_(e32|e64|dpp|sdwa)$", "", t[0])] += 1

@@ -23,6 +23,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = "_ZN4trew12exact_kernelILi3ELi0EmEEv"
 
 
+SCALAR_SRC = re.compile(r"^(s\d+|s\[\d+:\d+\]|vcc|vcc_lo|vcc_hi|exec|exec_lo|exec_hi|m0|ttmp\d+)$")
+
+
+def scalar_source(line):
+    """Does a VALU instruction read a scalar register (operands after the destination; carry-out / compare destinations are
+    not sources)?  Inline constants and literals are not scalar registers (measured full rate)."""
+    body = line.split(";")[0].strip()
+    t = body.split(None, 1)
+    if len(t) < 2 or not t[0].startswith("v_"):
+        return False
+    operands = [o.strip() for o in t[1].split(",")]
+    srcs = operands[1:]
+    if re.match(r"v_(add|sub|subrev)_co_u32|v_(addc|subb|subbrev)_co_u32|v_mad_u64_u32|v_div_scale", t[0]):
+        srcs = operands[2:]  # second operand is the carry-out
+    return any(SCALAR_SRC.match(o.split()[0]) for o in srcs if o)
+
+
 def static(out):
     d = tempfile.mkdtemp(prefix="trew_isa_")
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-function", "-Wno-pass-failed", "-save-temps",
@@ -52,6 +69,8 @@ def static(out):
         op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", t[0])
         if t[0].endswith("_dpp"):
             op += "_dpp"
+        elif scalar_source(line):
+            op += "+s"  # a scalar source operand: half rate whatever the opcode (tools/valu_rate.hip, "(sgpr)" entries)
         ops[cur][op] += 1
     json.dump({"kernel": KERNEL, "copies": copies, "ops": ops}, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, {r: sum(c.values()) for r, c in ops.items()})
@@ -88,6 +107,8 @@ def price(op, rates, unmeasured):
     """SIMD cycles per wave-instruction of a VALU opcode."""
     full, half = rates["classes"]["full_rate"], rates["classes"]["half_rate"]
     table = rates["cycles_per_wave_inst"]
+    if op.endswith("+s"):  # scalar source operand: never faster than half rate
+        return max(half, price(op[:-2], rates, unmeasured))
     base = op.replace("_dpp", "")
     if op.endswith("_dpp") and "v_mov_b32_dpp" in table:
         return table["v_or_b32_dpp" if base != "v_mov_b32" and "v_or_b32_dpp" in table else "v_mov_b32_dpp"]

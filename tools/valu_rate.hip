@@ -66,13 +66,38 @@
 #define OP_CMPEQ(a, b) "v_cmp_eq_u32 vcc, " a ", " b "\n"
 #define OP_CMP64(a, b) "v_cmp_lt_u64 vcc, " a ", " b "\n"
 
-enum { N_OPS = 38 };
+// round 4, second batch: three-operand adds / logic and packed 16-bit arithmetic (candidates for the prefilter's threshold tail)
+#define OP_ADD3(a, b) "v_add3_u32 " a ", " a ", " b ", " b "\n"
+#define OP_ANDOR(a, b) "v_and_or_b32 " a ", " a ", " b ", " b "\n"
+#define OP_OR3(a, b) "v_or3_b32 " a ", " a ", " b ", " b "\n"
+#define OP_PKADD(a, b) "v_pk_add_u16 " a ", " b ", " a "\n"
+#define OP_PKMAX(a, b) "v_pk_max_u16 " a ", " b ", " a "\n"
+#define OP_PKSUB(a, b) "v_pk_sub_u16 " a ", " b ", " a "\n"
+#define OP_SUBS(a, b) "v_sub_u32 " a ", %8, " b "\n"
+#define OP_CMPGTI(a, b) "v_cmp_gt_i32 vcc, 0, " a "\n"
+#define OP_LSHLADD(a, b) "v_lshl_add_u32 " a ", " b ", 16, " a "\n"
+
+// does a scalar source operand cost issue time?
+#define OP_ANDS(a, b) "v_and_b32 " a ", %8, " b "\n"
+#define OP_BITOP3S(a, b) "v_bitop3_b32 " a ", " a ", " b ", %8 bitop3:0x28\n"
+#define OP_BCNTS(a, b) "v_bcnt_u32_b32 " a ", " b ", %8\n"
+#define OP_XORS(a, b) "v_xor_b32 " a ", %8, " b "\n"
+
+#define OP_XORLIT(a, b) "v_xor_b32 " a ", 0x12345678, " b "\n"
+#define OP_XORINL(a, b) "v_xor_b32 " a ", 15, " b "\n"
+#define OP_ADDINL(a, b) "v_add_u32 " a ", 8, " b "\n"
+#define OP_XORVCC(a, b) "v_xor_b32 " a ", vcc_lo, " b "\n"
+
+enum { N_OPS = 55 };
 static const char *kNames[N_OPS] = {"v_xor_b32",     "v_alignbit_b32", "v_bcnt_u32_b32", "v_bitop3_b32",  "v_add_u32",      "v_lshrrev_b32", "v_lshl_or_b32",
                                     "v_max3_u32",    "v_sub_u32",      "v_and_b32",      "v_bfe_u32",     "v_perm_b32",     "v_cmp_le_u32",  "v_mov_b32",
                                     "v_lshrrev_b64", "v_lshlrev_b64",  "v_mad_u64_u32",  "v_add_co_u32",  "v_cndmask_b32",  "v_mbcnt_lo",    "v_ffbl_b32",
                                     "v_bfrev_b32",   "v_mul_lo_u32",   "v_sad_u8",       "v_dot4_u32_u8", "xor+alignbit+bcnt mix (the prefilter's k loop)",
                                     "v_max_u32",     "v_min_u32",      "v_or_b32",       "v_lshlrev_b32", "v_mul_u32_u24",  "v_mov_b32_dpp", "v_or_b32_dpp",
-                                    "v_writelane_b32", "v_cmp_eq_u32", "v_cmp_lt_u64",   "v_readlane_b32", "v_readfirstlane_b32"};
+                                    "v_writelane_b32", "v_cmp_eq_u32", "v_cmp_lt_u64",   "v_readlane_b32", "v_readfirstlane_b32",
+                                    "v_add3_u32",    "v_and_or_b32",   "v_or3_b32",      "v_pk_add_u16",  "v_pk_max_u16",   "v_pk_sub_u16",  "v_sub_u32 (sgpr)",
+                                    "v_cmp_gt_i32",  "v_lshl_add_u32", "v_and_b32 (sgpr)", "v_bitop3_b32 (sgpr)", "v_bcnt_u32_b32 (sgpr)", "v_xor_b32 (sgpr)",
+                                    "v_xor_b32 (literal)", "v_xor_b32 (inline constant)", "v_add_u32 (inline constant)", "v_xor_b32 (vcc_lo)"};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stamps, int iters, unsigned s) {
@@ -138,6 +163,23 @@ __global__ __launch_bounds__(256) void k(unsigned *out, unsigned long long *stam
                               : "s"(s)
                               : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
         }
+        if (OP == 38) { REP8(CHAIN8(OP_ADD3);) }
+        if (OP == 39) { REP8(CHAIN8(OP_ANDOR);) }
+        if (OP == 40) { REP8(CHAIN8(OP_OR3);) }
+        if (OP == 41) { REP8(CHAIN8(OP_PKADD);) }
+        if (OP == 42) { REP8(CHAIN8(OP_PKMAX);) }
+        if (OP == 43) { REP8(CHAIN8(OP_PKSUB);) }
+        if (OP == 44) { REP8(CHAIN8(OP_SUBS);) }
+        if (OP == 45) { REP8(CHAIN8(OP_CMPGTI);) }
+        if (OP == 46) { REP8(CHAIN8(OP_LSHLADD);) }
+        if (OP == 47) { REP8(CHAIN8(OP_ANDS);) }
+        if (OP == 48) { REP8(CHAIN8(OP_BITOP3S);) }
+        if (OP == 49) { REP8(CHAIN8(OP_BCNTS);) }
+        if (OP == 50) { REP8(CHAIN8(OP_XORS);) }
+        if (OP == 51) { REP8(CHAIN8(OP_XORLIT);) }
+        if (OP == 52) { REP8(CHAIN8(OP_XORINL);) }
+        if (OP == 53) { REP8(CHAIN8(OP_ADDINL);) }
+        if (OP == 54) { REP8(CHAIN8(OP_XORVCC);) }
         if (OP == 25) {
             // the instruction mix of one (k, word) of the prefilter's fast path: 2 alignbit, 2 xor, 1 and, 3 bcnt
             REP8(asm volatile("v_alignbit_b32 %4, %1, %0, %8\n v_alignbit_b32 %5, %3, %2, %8\n v_xor_b32 %4, %4, %0\n v_xor_b32 %5, %5, %2\n"

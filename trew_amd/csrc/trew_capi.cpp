@@ -306,9 +306,9 @@ extern "C" int trew_hip_init(const trew_hip_params *params, trew_hip_ctx **out) 
             if ((e = hipMalloc((void **) &s.d_ascii, p.max_batch_ascii_bytes + 256)) != hipSuccess) return bail("hipMalloc(text buffer)", e);
             if ((e = hipMemsetAsync(s.d_ascii, 0, p.max_batch_ascii_bytes + 256, ctx->fill_stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         }
-        if ((e = hipMalloc((void **) &s.d_thr, kThrRows * kThrRow * sizeof(int2))) != hipSuccess) return bail("hipMalloc(thresholds)", e);
-        if ((e = hipHostMalloc((void **) &s.h_thr, kThrRows * kThrRow * sizeof(int2) + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
-        s.h_seen = (u32 *) (s.h_thr + kThrRows * kThrRow);
+        if ((e = hipMalloc((void **) &s.d_thr, kThrTableBytes)) != hipSuccess) return bail("hipMalloc(thresholds)", e);
+        if ((e = hipHostMalloc((void **) &s.h_thr, kThrTableBytes + kDiagWords * 4, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc(thresholds)", e);
+        s.h_seen = (u32 *) ((char *) s.h_thr + kThrTableBytes);
         memset(s.h_seen, 0, kDiagWords * 4);
         if ((e = hipMalloc((void **) &s.d_wl, p.max_batch_reads * sizeof(u32))) != hipSuccess) return bail("hipMalloc(worklist)", e);
         if ((e = hipMalloc((void **) &s.d_wl_count, 2 * kWlCountBytes)) != hipSuccess) return bail("hipMalloc(wl_count)", e);
@@ -559,7 +559,7 @@ static int stage_thresholds(trew_hip_ctx *ctx, Slot &s, const DevBatch &db, cons
     if (s.thr_length != db.uniform_length) {
         HIPCHK(ctx, hipStreamSynchronize(s.stream));  // an earlier copy may still be reading the staging buffer
         fill_thresholds(ctx->dp, db.uniform_length, s.h_thr);
-        HIPCHK(ctx, hipMemcpyAsync(s.d_thr, s.h_thr, kThrRows * kThrRow * sizeof(int2), hipMemcpyHostToDevice, s.stream));
+        HIPCHK(ctx, hipMemcpyAsync(s.d_thr, s.h_thr, kThrTableBytes, hipMemcpyHostToDevice, s.stream));
         s.thr_length = db.uniform_length;
     }
     *out = s.d_thr;

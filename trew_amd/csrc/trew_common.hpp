@@ -19,7 +19,10 @@ constexpr int kMaxSlots = 6;        // segments per unit: short 3, pair 6, long 
 constexpr int kMaxSegBases = 1023;  // longest segment any kernel accepts (short mode rejects reads > 1000, kmer.cpp:1006-1009)
 constexpr int kTablePartBits = 9;   // low word bits that select the table partition (see table_add)
 constexpr int kThrRows = kMaxSlots + 2;  // rows of the threshold table: one per slot + one per pair of halves of unequal length (joint rows, fill_thresholds)
+constexpr int kThrJointRows = 4;    // behind those, four rows of int4 for the loop that judges both halves of a read at once: halves 0/1 and 2/3 of equal length, then of unequal length
 constexpr int kThrRow = 66;         // threshold-table entries per slot: k = 1..64, one of read-ahead padding, one to keep rows 16-byte aligned
+constexpr size_t kThrTableBytes = (size_t) kThrRows * kThrRow * 8 + (size_t) kThrJointRows * kThrRow * 16;
+constexpr int kThrNever = 1 << 20;  // a threshold nothing reaches (small enough to be doubled and tripled in the joint rows)
 
 struct DevParams {
     int min_mer, max_mer;

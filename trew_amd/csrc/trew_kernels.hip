@@ -72,7 +72,8 @@ int pick_nw(u32 max_seg_len) {
     return 32;
 }
 
-// Pass thresholds of the uniform-geometry fast path for one batch geometry: table[slot * kThrRow + k - 1] = {ithr, jthr}.
+// Pass thresholds of the uniform-geometry fast path for one batch geometry: table[slot * kThrRow + k - 1] = {ithr, jthr}
+// (kThrTableBytes in all: the int2 rows, then the joint loop's int4 rows).
 // Host side (single-precision multiply, the same IEEE operation the general path performs on the device).
 void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
     const int nslots = mode_slots(P.mode);
@@ -87,7 +88,7 @@ void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
         for (int k = 1; k <= kThrRow; k++) {
             const int W = (int) sg.len - k + 1;
             int2 th;
-            th.x = 0x7fffffff;  // nothing passes
+            th.x = kThrNever;  // nothing passes
             th.y = -1;
             if (slot < nslots && sg.valid && W > 0) {
                 const volatile float prod = (float) W * P.lowf;  // volatile: no contraction, no extended precision
@@ -110,7 +111,7 @@ void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
         const bool ok = 2 * p + 1 < nslots && a.valid && b.valid && b.len == a.len + 1;
         for (int k = 1; k <= kThrRow; k++) {
             int2 th;
-            th.x = 0x7fffffff;
+            th.x = kThrNever;
             th.y = -1;
             const int WA = (int) a.len - k + 1, WB = WA + 1;
             if (ok && WA > 0) {
@@ -121,6 +122,16 @@ void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table) {
                 th.y = Weff - th.x;
             }
             table[(kMaxSlots + p) * kThrRow + k - 1] = th;
+        }
+    }
+    // The joint loop's own rows (filter_halves_uni): per k {-2 ithr, -ithr, 3 ithr - jthr - 1, ithr} of the row it used to read --
+    // the starting values of its popcount chains and the constant of its bucket-00 test (halves_signs).
+    int4 *joint = (int4 *) (table + kThrRows * kThrRow);
+    for (int r = 0; r < kThrJointRows; r++) {
+        const int2 *src = table + (r < 2 ? 2 * r : kMaxSlots + (r - 2)) * kThrRow;
+        for (int k = 1; k <= kThrRow; k++) {
+            const int2 th = src[k - 1];
+            joint[r * kThrRow + k - 1] = make_int4(-2 * th.x, -th.x, 3 * th.x - th.y - 1, th.x);
         }
     }
 }

@@ -10,7 +10,7 @@ int pick_nw(u32 max_seg_len);
 
 hipError_t launch_filter(hipStream_t st, u32 n_cu, u32 max_seg_len, const DevParams &P, const DevBatch &B, u32 *wl, u32 *wl_count,
                          u32 wl_cap, u64 *dbg_masks, int dbg_slots, u32 *diag, const int2 *d_thr);
-void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table);  // kThrRows * kThrRow entries
+void fill_thresholds(const DevParams &P, u32 uniform_length, int2 *table);  // kThrTableBytes
 hipError_t launch_exact(hipStream_t st, u32 n_cu, u64 n_units, const DevParams &P, const DevBatch &B, const DevTableG1 &T,
                         const u32 *wl, u32 *wl_count, u32 *wl_count_next, u32 wl_cap, const SegResults &R, u32 cap, u32 rawwords,
                         u32 max_seg_len, bool share);  // share: leave half of the wave slots to a prefilter on another stream
