@@ -24,7 +24,7 @@ f = json.load(open(tmp))
 loop = max(f["loops"], key=lambda l: l["ops"].get("v_lshrrev_b64", 0))
 res = {"filter_kernel": {
     "half_rate_share_of_valu_insts": round(loop["valu_half_rate"] / loop["valu"], 3),
-    "from": "innermost loop %s of filter_kernel<3> (both halves of a read, one k per trip half): %d VALU = %d full-rate + %d half-rate, %d SALU, %d SMEM, %d branches" % (
+    "from": "innermost loop %s of filter_kernel<3> (both halves of a read, two k per trip; an instruction with a scalar source counts as half rate): %d VALU = %d full-rate + %d half-rate, %d SALU, %d SMEM, %d branches" % (
         loop["label"], loop["valu"], loop["valu_full_rate"], loop["valu_half_rate"], loop["salu"], loop["smem"], loop["branch"]),
     "loop": loop}}
 fns = ["eval_runsImEE", "eval_kImEE", "emit_kImEE", "stage_basesE", "9table_addENS", "eval_k_windowsImEE"]
