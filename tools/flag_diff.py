@@ -1,5 +1,6 @@
-"""tools/flag_diff.py PASSES: the same 12 M-read device batch PASSES times on alternating slots; the worklist of every pass is
-compared with the first one as a multiset -- prints units that are missing, extra or duplicated."""
+"""tools/flag_diff.py PASSES [short|pair|long]: the same device batch (12 M reads, 6 M pairs or 1 M long reads) PASSES times on
+alternating slots; the worklist of every pass is compared with the first one as a multiset -- prints units that are missing,
+extra or duplicated."""
 import collections
 import os
 import sys
@@ -9,16 +10,25 @@ import numpy as np  # noqa: E402
 import trew_amd as T  # noqa: E402
 
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+mode = sys.argv[2] if len(sys.argv) > 2 else "short"
 n, L, seed = 12_000_000, 150, 20250218
 stride = 3 * ((L + 31) // 32)
-with T.TrewHip(mode=T.MODE_SHORT, n_slots=2, max_batch_reads=n, max_batch_words=16, table_log2_slots=20) as t:
-    d = t.malloc(n * stride * 4 + 64)
-    t.synth_short_device(seed, 5_000_000_000, n, L, d)
+dev_mode = {"short": T.MODE_SHORT, "pair": T.MODE_PAIR, "long": T.MODE_LONG}[mode]
+with T.TrewHip(mode=dev_mode, n_slots=2, max_batch_reads=n, max_batch_words=16, table_log2_slots=20) as t:
+    if mode == "long":
+        batch, to_free, _ = t.synth_long_device(seed, 0, 1_000_000)
+    else:
+        d = t.malloc(n * stride * 4 + 64)
+        if mode == "pair":
+            t.synth_pair_device(seed, 5_000_000_000, n // 2, L, d)
+        else:
+            t.synth_short_device(seed, 5_000_000_000, n, L, d)
+        batch = t.device_uniform_batch(d, n, L)
     ref = None
     bad = 0
     for rep in range(passes):
         t.reset_tables()
-        t.submit(t.device_uniform_batch(d, n, L), rep & 1)
+        t.submit(batch, rep & 1)
         t.wait(rep & 1)
         if os.environ.get("FLAG_DIFF_COLLECT"):
             t.collect()
