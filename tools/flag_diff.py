@@ -30,9 +30,13 @@ with T.TrewHip(mode=dev_mode, n_slots=2, max_batch_reads=n, max_batch_words=16, 
         t.reset_tables()
         t.submit(batch, rep & 1)
         t.wait(rep & 1)
-        if os.environ.get("FLAG_DIFF_COLLECT"):
-            t.collect()
-            t.last_timing(rep & 1)
+        if os.environ.get("FLAG_DIFF_TABLES"):  # the tables as well (slower)
+            tab = t.collect()
+            if rep == 0:
+                ref_tab = tab
+            elif tab != ref_tab:
+                bad += 1
+                print("pass", rep, "tables differ")
         wl = np.sort(np.asarray(t.debug_worklist(rep & 1), dtype=np.int64))
         if ref is None:
             ref = wl
